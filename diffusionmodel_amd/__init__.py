@@ -1,0 +1,13 @@
+"""MI355X-native sampling hot path of the ragu812/diffusionModel latent-diffusion model.
+
+Same class and method names as the reference (LDM.py / src/main.rs); hand-written HIP kernels for
+gfx950 underneath (libldm_hip.so, C ABI in include/ldm_hip.h).
+"""
+from .weights import LDMConfig, make_synthetic_weights, unet_param_shapes
+from .modules import (Attention, DiffusionModel, ResidualBlock, ResiduelBlock, TimeAddition, UNet, Unet,
+                      philox_normal, sched_step, sin_time_addition)
+from .parallel import chain_range, gather_latents, sample_sharded
+
+__all__ = ["Attention", "DiffusionModel", "ResidualBlock", "ResiduelBlock", "TimeAddition", "UNet", "Unet",
+           "sin_time_addition", "sched_step", "philox_normal", "LDMConfig", "make_synthetic_weights",
+           "unet_param_shapes", "chain_range", "gather_latents", "sample_sharded"]

@@ -1,0 +1,141 @@
+// Shared declarations of the HIP library behind include/ldm_hip.h (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ldm_hip.h"
+
+namespace ldm {
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Last error text of the calling thread (returned by ldm_last_error()).
+void set_error(const std::string& msg);
+
+#define LDM_FAIL(code, msg)                                   \
+    do {                                                      \
+        ::ldm::set_error(std::string(__func__) + ": " + (msg)); \
+        return (code);                                        \
+    } while (0)
+
+#define LDM_REQUIRE(cond, msg) \
+    do {                       \
+        if (!(cond)) LDM_FAIL(LDM_ERR_INVALID, msg); \
+    } while (0)
+
+#define LDM_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) LDM_FAIL(LDM_ERR_HIP, std::string(#call) + " -> " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define LDM_TRY(call)          \
+    do {                       \
+        int r_ = (call);       \
+        if (r_ != LDM_OK) return r_; \
+    } while (0)
+
+// f32 -> bf16 round-to-nearest-even on the host (NaN kept quiet).
+inline bf16_t host_f2bf(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+inline float host_bf2f(bf16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tap convolution: one kernel family for conv3x3 (stride 1 and 2), the four sub-pixel phases of
+// convT4x4/stride 2, and conv1x1 over up to two channel-concatenated sources.
+// ---------------------------------------------------------------------------------------------
+enum ConvKind { CONV3x3_S1 = 0, CONV3x3_S2 = 1, CONVT4x4_S2 = 2, CONV1x1 = 3 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+// A convolution with its BatchNorm folded in, packed for the kernel (device memory).
+struct PackedConv {
+    int kind = 0;
+    int dtype = 0;          // LDM_F32 / LDM_BF16: element type of weights and activations
+    int cin = 0;            // padded total input channels (multiple of chunk)
+    int cout = 0;           // padded output channels (multiple of 64)
+    int ntaps = 0, nphase = 1;
+    void* w = nullptr;      // [phase][chunk][tap][cout][chunk elems], 16-byte pieces XOR-swizzled by (cout & 7)
+    float* bias = nullptr;  // [cout]
+    size_t w_bytes = 0;
+};
+
+struct ConvCall {
+    const void* in0 = nullptr;   // NHWC [B,Hin,Win,cin0]
+    const void* in1 = nullptr;   // optional second source (channels appended after in0's)
+    int cin0 = 0, cin1 = 0;
+    const void* res = nullptr;   // NHWC [B,Hout,Wout,cout], added before the activation
+    const float* tvec = nullptr; // added after the activation: tvec[img*t_img_stride + step*t_step_stride + c]
+    const int* step_ptr = nullptr;
+    int t_img_stride = 0, t_step_stride = 0;
+    void* out = nullptr;         // NHWC [B,Hout,Wout,cout]
+    int out_f32 = 0;             // write f32 although dtype is bf16
+    int act = ACT_NONE;
+    int B = 0, Hin = 0, Win = 0; // Hout/Wout follow from the kind
+};
+
+int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
+int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Attention core: softmax(q k^T / sqrt(C)) v over the tokens of one image, single head.
+// qkv NHWC-token layout [B, N, 3C] (q | k | v), out [B, N, C]; element type by dtype.
+// ---------------------------------------------------------------------------------------------
+int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Bandwidth-bound kernels.
+// ---------------------------------------------------------------------------------------------
+// NCHW f32 [B,C,H,W] -> NHWC [B,H,W,Cpad] (dtype elements, channels >= C zero filled)
+int launch_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int Cpad, int H, int W, hipStream_t s);
+// NHWC [B,H,W,Cpad] (f32 or bf16 by in_dtype) -> NCHW f32 [B,C,H,W]
+int launch_nhwc_to_nchw(const void* in, int in_dtype, float* out, int B, int C, int Cpad, int H, int W, hipStream_t s);
+// out[r, :] = act(in[r, :] @ W + b), W [K,N] f32 row-major; plain f32 FMA (time path, tiny)
+int launch_linear_f32(const float* in, const float* W, const float* b, float* out, int rows, int K, int N, int act,
+                      hipStream_t s);
+// sinusoidal embedding of integer timesteps (src/main.rs:309-335)
+int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s);
+
+struct SchedArgs {
+    float* z;              // [n] f32 state, updated in place
+    const void* eps;       // [n] f32 or bf16 (eps_dtype)
+    int eps_dtype;
+    const float* noise;    // [steps][n] f32 or null (then Philox when sigma != 0)
+    void* z_lowp;          // optional bf16 copy of the new state (next UNet input) or null
+    const float* coef;     // [steps][8] rows: sa, s1m, c1, c2, sigma, mode, last, 0; null: use cval
+    float cval[8];         // the row by value, for a single call
+    const int* step_ptr;   // device step counter (row of coef / noise); null: step 0
+    long n;                // elements per call (all chains, padded channels included)
+    long pix_per_chain;    // pixels per chain (H*W); the state is NHWC with cpad4*4 channels per pixel
+    int c4, cpad4;         // real and padded channel count / 4; noise group = pixel * c4 + channel / 4
+    unsigned long long seed;
+    unsigned int chain0;   // global index of the first chain held by this process
+    const unsigned int* rng;   // optional device words {seed low, seed high, chain0}: override the two above
+};
+// ctl[0] = 0 (step counter), ctl[1..3] = {seed low, seed high, chain0}
+int launch_set_ctl(int* ctl, unsigned long long seed, unsigned int chain0, hipStream_t s);
+int launch_sched_step(const SchedArgs& a, hipStream_t s);
+int launch_step_advance(int* step_ptr, hipStream_t s);
+int launch_set_int(int* p, int v, hipStream_t s);
+// z[n] <- counter-based normals of `step` (0xFFFFFFFF = initial latent), NHWC chains
+int launch_philox_init(float* z, void* z_lowp, long n, long pix_per_chain, int c4, int cpad4, unsigned long long seed,
+                       unsigned int chain0, unsigned int step, hipStream_t s);
+// the same field written NCHW f32 [B,C,H,W]
+int launch_philox_nchw(float* out, int B, int C, int H, int W, unsigned long long seed, unsigned int chain0,
+                       unsigned int step, hipStream_t s);
+int launch_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);
+
+}  // namespace ldm

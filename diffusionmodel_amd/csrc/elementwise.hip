@@ -1,0 +1,381 @@
+// Bandwidth-bound kernels of the sampling loop (gfx950): the fused DDPM/DDIM scheduler update
+// (src/main.rs:712-756,765), layout changes at the loop boundary, the sinusoidal timestep embedding
+// (src/main.rs:309-335), the tiny f32 Linears of the time path (src/main.rs:302-306,377-378) and a
+// counter-based normal generator.  All of them stream 16 bytes per lane.
+#include "common.h"
+
+namespace ldm {
+
+__device__ __forceinline__ bf16_t ew_f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float ew_bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// Philox-4x32-10 and Box-Muller: four standard normals per counter.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                              unsigned int k0, unsigned int k1, unsigned int out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
+        const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned int)p1;
+        c3 = (unsigned int)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ f32x4 philox_normal4(unsigned int group, unsigned int step, unsigned int chain,
+                                                unsigned long long seed) {
+    unsigned int r[4];
+    philox4x32_10(group, step, chain, 0x4C444D31u, (unsigned int)seed, (unsigned int)(seed >> 32), r);
+    const float s = 5.9604644775390625e-08f;   // 2^-24
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s, u1 = ((float)(r[1] >> 8) + 0.5f) * s;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s, u3 = ((float)(r[3] >> 8) + 0.5f) * s;
+    const float two_pi = 6.283185307179586f;
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    f32x4 n;
+    n[0] = ra * cosf(two_pi * u1);
+    n[1] = ra * sinf(two_pi * u1);
+    n[2] = rb * cosf(two_pi * u3);
+    n[3] = rb * sinf(two_pi * u3);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scheduler step.  Per element, f32, in the reference's operation order:
+//   x0 = (z - eps * s1m) / sa
+//   mode 0 (DDPM, src/main.rs:752-756): z' = (x0 * c1 + z * c2) + sigma * n     (last step: z' = x0)
+//   mode 1 (DDIM, eta = 0):             z' = x0 * c1 + eps * c2
+// coef row = {sa, s1m, c1, c2, sigma, mode, last, 0}.  Contraction to FMA is disabled so that the
+// result is the same sequence of f32 roundings as the CPU statement.
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void sched_step_kernel(const SchedArgs a) {
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    const float* cf = a.coef ? a.coef + (size_t)step * 8 : a.cval;
+    const float sa = cf[0], s1m = cf[1], c1 = cf[2], c2 = cf[3], sigma = cf[4];
+    const int mode = (int)cf[5], last = (int)cf[6];
+    const long n4 = a.n >> 2;
+    const long cg = a.pix_per_chain * a.cpad4;   // padded groups of 4 per chain
+    const float* noise = a.noise ? a.noise + (size_t)step * a.n : nullptr;
+    unsigned long long seed = a.seed;
+    unsigned int chain0 = a.chain0;
+    if (a.rng) {
+        seed = (unsigned long long)a.rng[0] | ((unsigned long long)a.rng[1] << 32);
+        chain0 = a.rng[2];
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 z = *(const f32x4*)(a.z + i * 4);
+        f32x4 e;
+        if (a.eps_dtype == LDM_BF16) {
+            const uint2 r = *(const uint2*)((const char*)a.eps + i * 8);
+            e[0] = ew_bf2f((bf16_t)(r.x & 0xffffu)); e[1] = ew_bf2f((bf16_t)(r.x >> 16));
+            e[2] = ew_bf2f((bf16_t)(r.y & 0xffffu)); e[3] = ew_bf2f((bf16_t)(r.y >> 16));
+        } else {
+            e = *(const f32x4*)((const float*)a.eps + i * 4);
+        }
+        f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+        if (mode == 0 && !last) {
+            if (noise) {
+                nz = *(const f32x4*)(noise + i * 4);
+            } else {
+                const long chain = i / cg;
+                const long rem = i - chain * cg;
+                const long pix = rem / a.cpad4;
+                const int cq = (int)(rem - pix * a.cpad4);
+                if (cq < a.c4)
+                    nz = philox_normal4((unsigned int)(pix * a.c4 + cq), (unsigned int)step,
+                                        chain0 + (unsigned int)chain, seed);
+            }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = (z[q] - e[q] * s1m) / sa;
+            float r;
+            if (last) r = x0;
+            else if (mode == 0) r = (x0 * c1 + z[q] * c2) + sigma * nz[q];
+            else r = x0 * c1 + e[q] * c2;
+            o[q] = r;
+        }
+        *(f32x4*)(a.z + i * 4) = o;
+        if (a.z_lowp) {
+            uint2 w;
+            w.x = (unsigned int)ew_f2bf(o[0]) | ((unsigned int)ew_f2bf(o[1]) << 16);
+            w.y = (unsigned int)ew_f2bf(o[2]) | ((unsigned int)ew_f2bf(o[3]) << 16);
+            *(uint2*)((char*)a.z_lowp + i * 8) = w;
+        }
+    }
+}
+#pragma clang fp contract(on)
+
+static inline int ew_grid(long work_items) {
+    long g = (work_items + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int launch_sched_step(const SchedArgs& a, hipStream_t s) {
+    LDM_REQUIRE(a.z && a.eps, "null pointer");
+    LDM_REQUIRE(a.n > 0 && a.pix_per_chain > 0 && a.c4 > 0 && a.cpad4 >= a.c4 &&
+                    a.n % (a.pix_per_chain * a.cpad4 * 4) == 0,
+                "element count must be a whole number of chains");
+    hipLaunchKernelGGL(sched_step_kernel, dim3(ew_grid(a.n / 4)), dim3(256), 0, s, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+__global__ void step_advance_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = *p + 1; }
+__global__ void set_int_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+
+int launch_step_advance(int* p, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, p);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+__global__ void set_ctl_kernel(int* ctl, unsigned int s0, unsigned int s1, unsigned int chain0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = (int)s0;
+        ctl[2] = (int)s1;
+        ctl[3] = (int)chain0;
+    }
+}
+int launch_set_ctl(int* ctl, unsigned long long seed, unsigned int chain0, hipStream_t s) {
+    hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(64), 0, s, ctl, (unsigned int)seed, (unsigned int)(seed >> 32), chain0);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+int launch_set_int(int* p, int v, hipStream_t s) {
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, s, p, v);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+__global__ __launch_bounds__(256) void philox_init_kernel(float* z, void* z_lowp, long n4, long pix_per_chain, int c4,
+                                                          int cpad4, unsigned long long seed, unsigned int chain0,
+                                                          unsigned int step) {
+    const long cg = pix_per_chain * cpad4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long chain = i / cg;
+        const long rem = i - chain * cg;
+        const long pix = rem / cpad4;
+        const int cq = (int)(rem - pix * cpad4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (cq < c4) o = philox_normal4((unsigned int)(pix * c4 + cq), step, chain0 + (unsigned int)chain, seed);
+        *(f32x4*)(z + i * 4) = o;
+        if (z_lowp) {
+            uint2 w;
+            w.x = (unsigned int)ew_f2bf(o[0]) | ((unsigned int)ew_f2bf(o[1]) << 16);
+            w.y = (unsigned int)ew_f2bf(o[2]) | ((unsigned int)ew_f2bf(o[3]) << 16);
+            *(uint2*)((char*)z_lowp + i * 8) = w;
+        }
+    }
+}
+
+int launch_philox_init(float* z, void* z_lowp, long n, long pix_per_chain, int c4, int cpad4, unsigned long long seed,
+                       unsigned int chain0, unsigned int step, hipStream_t s) {
+    LDM_REQUIRE(z && n > 0 && pix_per_chain > 0 && c4 > 0 && cpad4 >= c4 && n % (pix_per_chain * cpad4 * 4) == 0,
+                "bad arguments");
+    hipLaunchKernelGGL(philox_init_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, s, z, z_lowp, n / 4, pix_per_chain, c4,
+                       cpad4, seed, chain0, step);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// One thread per group of 4 channels of one pixel; writes the four NCHW elements.
+__global__ __launch_bounds__(256) void philox_nchw_kernel(float* out, long ngroups, int c4, long HW,
+                                                          unsigned long long seed, unsigned int chain0,
+                                                          unsigned int step) {
+    const long per_chain = HW * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += (long)gridDim.x * blockDim.x) {
+        const long chain = i / per_chain;
+        const long grp = i - chain * per_chain;
+        const long pix = grp / c4;
+        const int cq = (int)(grp - pix * c4);
+        const f32x4 o = philox_normal4((unsigned int)grp, step, chain0 + (unsigned int)chain, seed);
+        float* dst = out + ((size_t)chain * c4 * 4 + (size_t)cq * 4) * HW + pix;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(size_t)q * HW] = o[q];
+    }
+}
+
+int launch_philox_nchw(float* out, int B, int C, int H, int W, unsigned long long seed, unsigned int chain0,
+                       unsigned int step, hipStream_t s) {
+    LDM_REQUIRE(out && B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "bad arguments (C must be a multiple of 4)");
+    const long ng = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(philox_nchw_kernel, dim3(ew_grid(ng)), dim3(256), 0, s, out, ng, C / 4, (long)H * W, seed, chain0,
+                       step);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, char* out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(in + i * 4);
+        uint2 w;
+        w.x = (unsigned int)ew_f2bf(v[0]) | ((unsigned int)ew_f2bf(v[1]) << 16);
+        w.y = (unsigned int)ew_f2bf(v[2]) | ((unsigned int)ew_f2bf(v[3]) << 16);
+        *(uint2*)(out + i * 8) = w;
+    }
+}
+
+int launch_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t s) {
+    LDM_REQUIRE(in && out && n > 0 && n % 4 == 0, "bad arguments");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, s, in, (char*)out, n / 4);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW f32 <-> NHWC (f32 / bf16) through a 32(channel) x 64(pixel) LDS tile: reads and writes are
+// both contiguous along the fast axis of their tensor.
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, TO* __restrict__ out, int C,
+                                                           int Cpad, long HW) {
+    __shared__ float tile[32][65];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const float* src = in + (size_t)b * C * HW;
+    TO* dst = out + (size_t)b * HW * Cpad;
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {
+        const int c = k >> 6, p = k & 63;
+        float v = 0.f;
+        if (c0 + c < C && p0 + p < HW) v = src[(size_t)(c0 + c) * HW + p0 + p];
+        tile[c][p] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {
+        const int p = k >> 5, c = k & 31;
+        if (c0 + c < Cpad && p0 + p < HW) {
+            const float v = tile[c][p];
+            if constexpr (sizeof(TO) == 2) dst[(size_t)(p0 + p) * Cpad + c0 + c] = ew_f2bf(v);
+            else dst[(size_t)(p0 + p) * Cpad + c0 + c] = v;
+        }
+    }
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const TI* __restrict__ in, float* __restrict__ out, int C,
+                                                           int Cpad, long HW) {
+    __shared__ float tile[32][65];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const TI* src = in + (size_t)b * HW * Cpad;
+    float* dst = out + (size_t)b * C * HW;
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {
+        const int p = k >> 5, c = k & 31;
+        float v = 0.f;
+        if (c0 + c < Cpad && p0 + p < HW) {
+            if constexpr (sizeof(TI) == 2) v = ew_bf2f(src[(size_t)(p0 + p) * Cpad + c0 + c]);
+            else v = src[(size_t)(p0 + p) * Cpad + c0 + c];
+        }
+        tile[c][p] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {
+        const int c = k >> 6, p = k & 63;
+        if (c0 + c < C && p0 + p < HW) dst[(size_t)(c0 + c) * HW + p0 + p] = tile[c][p];
+    }
+}
+
+int launch_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int Cpad, int H, int W, hipStream_t s) {
+    LDM_REQUIRE(in && out && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "bad arguments");
+    LDM_REQUIRE(B <= 65535, "batch too large for one launch");
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((Cpad + 31) / 32), (unsigned)B);
+    if (dtype == LDM_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, C, Cpad, HW);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, C, Cpad, HW);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+int launch_nhwc_to_nchw(const void* in, int in_dtype, float* out, int B, int C, int Cpad, int H, int W, hipStream_t s) {
+    LDM_REQUIRE(in && out && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "bad arguments");
+    LDM_REQUIRE(B <= 65535, "batch too large for one launch");
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)B);
+    if (in_dtype == LDM_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, out, C, Cpad, HW);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, C, Cpad, HW);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time path (tiny): out[r, n] = act(sum_k in[r,k] * W[k,n] + b[n]).  One thread per output column,
+// 8 rows per block kept in LDS; W rows are read coalesced.  f32 FMA chain in k order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ out, int rows,
+                                                         int K, int N, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* xs = (float*)smem_raw;   // [8][K]
+    const int r0 = blockIdx.y * 8;
+    const int nr = min(8, rows - r0);
+    for (int k = threadIdx.x; k < nr * K; k += 256) xs[k] = in[(size_t)r0 * K + k];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = W[(size_t)k * N + n];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < nr) acc[r] = fmaf(xs[r * K + k], w, acc[r]);
+    }
+    const float bias = b ? b[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < nr) {
+            float v = acc[r] + bias;
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_SILU) v = v / (1.0f + expf(-v));
+            out[(size_t)(r0 + r) * N + n] = v;
+        }
+    }
+}
+
+int launch_linear_f32(const float* in, const float* W, const float* b, float* out, int rows, int K, int N, int act,
+                      hipStream_t s) {
+    LDM_REQUIRE(in && W && out && rows > 0 && K > 0 && N > 0, "bad arguments");
+    LDM_REQUIRE((size_t)8 * K * 4 <= 64 * 1024, "K too large for the time-path Linear");
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((rows + 7) / 8));
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), (size_t)8 * K * 4, s, in, W, b, out, rows, K, N, act);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// emb[r, i] = sin(t_r * f_i), emb[r, half + i] = cos(t_r * f_i), f_i = exp(-(i * 4 ln10 / half))
+__global__ void sin_embed_kernel(const int* __restrict__ t, int rows, int dim, float* __restrict__ out) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * half) return;
+    const int r = idx / half, i = idx - r * half;
+    const float expo = (float)i * 4.0f * 2.302585092994046f / (float)half;
+    const float f = expf(-expo);
+    const float arg = (float)t[r] * f;
+    out[(size_t)r * dim + i] = sinf(arg);
+    out[(size_t)r * dim + half + i] = cosf(arg);
+}
+
+int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s) {
+    LDM_REQUIRE(t && out && rows > 0 && dim > 0 && dim % 2 == 0, "bad arguments");
+    const int n = rows * (dim / 2);
+    hipLaunchKernelGGL(sin_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, rows, dim, out);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+}  // namespace ldm

@@ -1,0 +1,898 @@
+// Host side of libldm_hip.so: parameter staging, BatchNorm folding and weight packing, the UNet
+// forward as a sequence of kernel launches, the sampling loop with its hipGraph, and the C ABI of
+// include/ldm_hip.h.  Reference: Unet / ResidualBlock / Attention / TimeAddition / DiffusionModel in
+// src/main.rs:237-335, 336-527, 553-583, 631-633, 681-777.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace ldm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int round_up_i(int v, int a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// device allocations owned by a module / sampler
+// ---------------------------------------------------------------------------------------------
+struct DevPool {
+    std::vector<void*> ptrs;
+    ~DevPool() { release(); }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+    int alloc(void** out, size_t bytes) {
+        void* p = nullptr;
+        LDM_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        ptrs.push_back(p);
+        *out = p;
+        return LDM_OK;
+    }
+    int upload(void** out, const void* host, size_t bytes) {
+        LDM_TRY(alloc(out, bytes));
+        LDM_HIP(hipMemcpy(*out, host, bytes, hipMemcpyHostToDevice));
+        return LDM_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// schedule, f32, operation order of src/main.rs:553-583 and :712-747
+// ---------------------------------------------------------------------------------------------
+static void host_betas(int T, std::vector<float>& b) {
+    b.resize(T);
+    const float b0 = 1e-4f, b1 = 0.02f;
+    const int dm = T - 1 > 1 ? T - 1 : 1;
+    const float den = (float)dm;
+    for (int i = 0; i < T; ++i) {
+        const float ratio = (float)i / den;
+        float beta = b0 + (b1 - b0) * ratio;
+        if (beta < 1e-6f) beta = 1e-6f;
+        if (beta > 0.999f) beta = 0.999f;
+        b[i] = beta;
+    }
+}
+static void host_alpha_bars(int T, std::vector<float>& ab) {
+    std::vector<float> b;
+    host_betas(T, b);
+    ab.resize(T);
+    float c = 1.0f;
+    for (int i = 0; i < T; ++i) {
+        const float a = 1.0f - b[i];
+        c = c * a;
+        ab[i] = c;
+    }
+}
+static void host_ddpm_coef(int T, std::vector<float>& tab) {   // [T][5]
+    std::vector<float> b, ab;
+    host_betas(T, b);
+    host_alpha_bars(T, ab);
+    tab.assign((size_t)T * 5, 0.f);
+    for (int i = 0; i < T; ++i) {
+        const float a_t = ab[i], b_t = b[i];
+        float* r = &tab[(size_t)i * 5];
+        r[0] = sqrtf(a_t);
+        const float om_t = a_t * -1.0f + 1.0f;
+        r[1] = sqrtf(om_t);
+        if (i > 0) {
+            const float a_p = ab[i - 1];
+            const float om_p = a_p * -1.0f + 1.0f;
+            const float den = om_t + 1e-8f;
+            const float var = (om_p / den) * b_t;
+            r[4] = sqrtf(var);
+            r[2] = (sqrtf(a_p) * b_t) / den;
+            r[3] = (sqrtf(1.0f - b_t) * om_p) / den;
+        } else {
+            r[2] = 1.0f; r[3] = 0.0f; r[4] = 0.0f;
+        }
+    }
+}
+static int host_ddim_ts(int T, int steps, std::vector<int>& ts) {
+    LDM_REQUIRE(steps >= 1 && steps <= T, "ddim steps must be in [1, num_time]");
+    const int stride = T / steps;
+    ts.resize(steps);
+    for (int k = 0; k < steps; ++k) ts[k] = (steps - 1 - k) * stride;
+    return LDM_OK;
+}
+static int host_ddim_coef(int T, int steps, std::vector<float>& tab) {   // [steps][5]
+    std::vector<float> ab;
+    host_alpha_bars(T, ab);
+    std::vector<int> ts;
+    LDM_TRY(host_ddim_ts(T, steps, ts));
+    const int stride = T / steps;
+    tab.assign((size_t)steps * 5, 0.f);
+    for (int k = 0; k < steps; ++k) {
+        const int t = ts[k];
+        const float a_t = ab[t];
+        const float a_p = t - stride >= 0 ? ab[t - stride] : 1.0f;
+        float* r = &tab[(size_t)k * 5];
+        r[0] = sqrtf(a_t);
+        r[1] = sqrtf(a_t * -1.0f + 1.0f);
+        r[2] = sqrtf(a_p);
+        r[3] = sqrtf(a_p * -1.0f + 1.0f);
+    }
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing for the tap-convolution kernel
+// ---------------------------------------------------------------------------------------------
+struct PackSpec {
+    int kind = 0, dtype = 0;
+    int cout = 0;                 // real output channels
+    std::vector<int> src;         // real channels of each source (1 or 2 sources)
+    int src0_padto = 0;           // pad source 0 to this many channels (0: to the kernel's channel chunk)
+    std::function<float(int phase, int tap, int co, int ci)> w;   // ci over the concatenated real channels
+    std::function<float(int co)> bias;
+};
+
+static int pack_conv(const PackSpec& sp, DevPool& pool, PackedConv* pc, int* src_pad /*[2]*/) {
+    const int es = sp.dtype == LDM_BF16 ? 2 : 4;
+    const int ck = 128 / es, epp = 16 / es;
+    LDM_REQUIRE(sp.src.size() == 1 || sp.src.size() == 2, "one or two sources");
+    int pad[2] = {0, 0}, off[2] = {0, 0}, ch0[2] = {0, 0};
+    int nchunks = 0, real_off = 0;
+    for (size_t s = 0; s < sp.src.size(); ++s) {
+        pad[s] = round_up_i(sp.src[s], ck);
+        if (s == 0 && sp.src0_padto > 0) {
+            LDM_REQUIRE(sp.src0_padto % ck == 0 && sp.src0_padto >= sp.src[0], "bad channel padding");
+            pad[0] = sp.src0_padto;
+        }
+        off[s] = real_off;
+        ch0[s] = nchunks;
+        real_off += sp.src[s];
+        nchunks += pad[s] / ck;
+    }
+    pc->kind = sp.kind;
+    pc->dtype = sp.dtype;
+    pc->cin = pad[0] + pad[1];
+    pc->cout = round_up_i(sp.cout, 64);
+    pc->nphase = sp.kind == CONVT4x4_S2 ? 4 : 1;
+    pc->ntaps = (sp.kind == CONV3x3_S1 || sp.kind == CONV3x3_S2) ? 9 : (sp.kind == CONVT4x4_S2 ? 4 : 1);
+    const size_t nel = (size_t)pc->nphase * nchunks * pc->ntaps * pc->cout * ck;
+    std::vector<float> wf(sp.dtype == LDM_F32 ? nel : 0);
+    std::vector<bf16_t> wh(sp.dtype == LDM_BF16 ? nel : 0);
+    for (int ph = 0; ph < pc->nphase; ++ph)
+        for (int c = 0; c < nchunks; ++c) {
+            const int s = (sp.src.size() == 2 && c >= ch0[1]) ? 1 : 0;
+            for (int t = 0; t < pc->ntaps; ++t)
+                for (int co = 0; co < pc->cout; ++co) {
+                    const size_t rowbase = ((((size_t)ph * nchunks + c) * pc->ntaps + t) * pc->cout + co) * ck;
+                    for (int e = 0; e < ck; ++e) {
+                        const int cs = (c - ch0[s]) * ck + e;
+                        float v = 0.f;
+                        if (co < sp.cout && cs < sp.src[s]) v = sp.w(ph, t, co, off[s] + cs);
+                        const int piece = e / epp;
+                        const size_t pos = rowbase + (size_t)((piece ^ (co & 7)) * epp + e % epp);
+                        if (sp.dtype == LDM_BF16) wh[pos] = host_f2bf(v);
+                        else wf[pos] = v;
+                    }
+                }
+        }
+    std::vector<float> bias(pc->cout, 0.f);
+    for (int co = 0; co < sp.cout; ++co) bias[co] = sp.bias(co);
+    pc->w_bytes = nel * es;
+    LDM_TRY(pool.upload(&pc->w, sp.dtype == LDM_BF16 ? (const void*)wh.data() : (const void*)wf.data(), pc->w_bytes));
+    LDM_TRY(pool.upload((void**)&pc->bias, bias.data(), bias.size() * 4));
+    if (src_pad) { src_pad[0] = pad[0]; src_pad[1] = pad[1]; }
+    return LDM_OK;
+}
+
+}  // namespace ldm
+
+using namespace ldm;
+
+// ---------------------------------------------------------------------------------------------
+// modules
+// ---------------------------------------------------------------------------------------------
+struct ResBlockP {
+    PackedConv c1, c2;
+    int C = 0;
+    int tv_off = 0;   // offset of this block's time vector inside a row of the time-vector table
+};
+struct AttnP {
+    PackedConv qkv, out;
+    int C = 0;
+};
+
+struct UnetBufs {   // NHWC activation buffers of one forward at fixed (B, H, W)
+    void *xin = nullptr, *eps = nullptr;
+    void *a1 = nullptr, *b1 = nullptr, *s1 = nullptr;
+    void *a2 = nullptr, *b2 = nullptr, *s2 = nullptr;
+    void *a3 = nullptr, *b3 = nullptr, *c3 = nullptr, *qkv3 = nullptr, *att3 = nullptr;
+    void *qkv2 = nullptr, *att2 = nullptr;
+    float *sinemb = nullptr, *h1 = nullptr, *temb = nullptr, *tvec = nullptr;   // time path, `rows` rows
+    size_t bytes = 0;
+};
+
+struct ldm_module {
+    int kind = 0, dtype = 0, in_ch = 0, te = 0;
+    int ch[3] = {64, 128, 256};
+    bool scaled = false, finalized = false;
+    std::map<std::string, std::vector<float>> params;
+    DevPool pool;
+    // packed network
+    int clp = 0;   // latent channels padded to the kernel's channel chunk
+    PackedConv down1, down2, down3, up1, up_conv1, up2, up_conv2, out_conv;
+    ResBlockP rb[7];
+    AttnP mid_atten, up_atten;
+    float *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twt = nullptr, *tbt = nullptr;
+    int tv_total = 0;
+    // grow-on-demand workspace for the module-level forwards
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    ~ldm_module() { if (ws) (void)hipFree(ws); }
+};
+
+static const char* kResNames[7] = {"down_res1", "down_res2", "down_res3", "mid_res1", "mid_res2", "up_res1", "up_res2"};
+
+static int es_of(int dtype) { return dtype == LDM_BF16 ? 2 : 4; }
+
+static int get_param(ldm_module* m, const std::string& name, size_t numel, const std::vector<float>** out) {
+    auto it = m->params.find(name);
+    if (it == m->params.end()) LDM_FAIL(LDM_ERR_STATE, "parameter '" + name + "' was not set");
+    if (it->second.size() != numel)
+        LDM_FAIL(LDM_ERR_INVALID, "parameter '" + name + "' has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(numel));
+    *out = &it->second;
+    return LDM_OK;
+}
+
+// conv (+ optional BatchNorm) -> PackedConv.  prefix "" means the names are used without a leading dot.
+static std::string pjoin(const std::string& prefix, const std::string& leaf) { return prefix.empty() ? leaf : prefix + "." + leaf; }
+
+static int pack_conv3x3(ldm_module* m, const std::string& conv, const std::string& bn, int cin, int cout, int stride,
+                        PackedConv* pc, int cin_padto = 0) {
+    const std::vector<float>*w, *b, *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+    LDM_TRY(get_param(m, pjoin(conv, "weight"), (size_t)cout * cin * 9, &w));
+    LDM_TRY(get_param(m, pjoin(conv, "bias"), cout, &b));
+    std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+    if (!bn.empty()) {
+        LDM_TRY(get_param(m, pjoin(bn, "gamma"), cout, &g));
+        LDM_TRY(get_param(m, pjoin(bn, "beta"), cout, &be));
+        LDM_TRY(get_param(m, pjoin(bn, "running_mean"), cout, &mu));
+        LDM_TRY(get_param(m, pjoin(bn, "running_var"), cout, &var));
+        for (int c = 0; c < cout; ++c) {
+            // y = (conv + b - mean) / sqrt(var + eps) * gamma + beta
+            const double s = (double)(*g)[c] / std::sqrt((double)(*var)[c] + 1e-5);
+            scale[c] = (float)s;
+            shift[c] = (float)(((double)(*b)[c] - (double)(*mu)[c]) * s + (double)(*be)[c]);
+        }
+    } else {
+        for (int c = 0; c < cout; ++c) shift[c] = (*b)[c];
+    }
+    PackSpec sp;
+    sp.kind = stride == 2 ? CONV3x3_S2 : CONV3x3_S1;
+    sp.dtype = m->dtype;
+    sp.cout = cout;
+    sp.src = {cin};
+    sp.src0_padto = cin_padto;
+    sp.w = [&](int, int tap, int co, int ci) { return (*w)[((size_t)co * cin + ci) * 9 + tap] * scale[co]; };
+    sp.bias = [&](int co) { return shift[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+static int pack_convT(ldm_module* m, const std::string& name, int cin, int cout, PackedConv* pc) {
+    const std::vector<float>*w, *b;
+    LDM_TRY(get_param(m, pjoin(name, "weight"), (size_t)cin * cout * 16, &w));
+    LDM_TRY(get_param(m, pjoin(name, "bias"), cout, &b));
+    PackSpec sp;
+    sp.kind = CONVT4x4_S2;
+    sp.dtype = m->dtype;
+    sp.cout = cout;
+    sp.src = {cin};
+    // out[2i+py, 2j+px] += in[i - 1 + py + ta, j - 1 + px + tb] * W[ci][co][3 - py - 2ta][3 - px - 2tb]
+    sp.w = [&](int ph, int tap, int co, int ci) {
+        const int py = ph >> 1, px = ph & 1, ta = tap >> 1, tb = tap & 1;
+        const int ky = 3 - py - 2 * ta, kx = 3 - px - 2 * tb;
+        return (*w)[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+    };
+    sp.bias = [&](int co) { return (*b)[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+static int pack_conv1x1_cat(ldm_module* m, const std::string& name, int cin0, int cin1, int cout, PackedConv* pc) {
+    const std::vector<float>*w, *b;
+    const int cin = cin0 + cin1;
+    LDM_TRY(get_param(m, pjoin(name, "weight"), (size_t)cout * cin, &w));
+    LDM_TRY(get_param(m, pjoin(name, "bias"), cout, &b));
+    PackSpec sp;
+    sp.kind = CONV1x1;
+    sp.dtype = m->dtype;
+    sp.cout = cout;
+    sp.src = {cin0, cin1};
+    sp.w = [&](int, int, int co, int ci) { return (*w)[(size_t)co * cin + ci]; };
+    sp.bias = [&](int co) { return (*b)[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+static int pack_attention(ldm_module* m, const std::string& prefix, int C, AttnP* ap) {
+    const std::vector<float>*wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+    LDM_TRY(get_param(m, pjoin(prefix, "question.weight"), (size_t)C * C, &wq));
+    LDM_TRY(get_param(m, pjoin(prefix, "question.bias"), C, &bq));
+    LDM_TRY(get_param(m, pjoin(prefix, "key.weight"), (size_t)C * C, &wk));
+    LDM_TRY(get_param(m, pjoin(prefix, "key.bias"), C, &bk));
+    LDM_TRY(get_param(m, pjoin(prefix, "val.weight"), (size_t)C * C, &wv));
+    LDM_TRY(get_param(m, pjoin(prefix, "val.bias"), C, &bv));
+    LDM_TRY(get_param(m, pjoin(prefix, "out.weight"), (size_t)C * C, &wo));
+    LDM_TRY(get_param(m, pjoin(prefix, "out.bias"), C, &bo));
+    ap->C = C;
+    PackSpec sp;
+    sp.kind = CONV1x1;
+    sp.dtype = m->dtype;
+    sp.cout = 3 * C;
+    sp.src = {C};
+    // Linear weights are [d_in, d_out]
+    sp.w = [&](int, int, int co, int ci) {
+        const std::vector<float>* ws[3] = {wq, wk, wv};
+        return (*ws[co / C])[(size_t)ci * C + co % C];
+    };
+    sp.bias = [&](int co) {
+        const std::vector<float>* bs[3] = {bq, bk, bv};
+        return (*bs[co / C])[co % C];
+    };
+    LDM_TRY(pack_conv(sp, m->pool, &ap->qkv, nullptr));
+    PackSpec so;
+    so.kind = CONV1x1;
+    so.dtype = m->dtype;
+    so.cout = C;
+    so.src = {C};
+    so.w = [&](int, int, int co, int ci) { return (*wo)[(size_t)ci * C + co]; };
+    so.bias = [&](int co) { return (*bo)[co]; };
+    return pack_conv(so, m->pool, &ap->out, nullptr);
+}
+
+static int pack_resblock(ldm_module* m, const std::string& prefix, int C, ResBlockP* rp) {
+    rp->C = C;
+    LDM_TRY(pack_conv3x3(m, pjoin(prefix, "conv1"), pjoin(prefix, "bn1"), C, C, 1, &rp->c1));
+    LDM_TRY(pack_conv3x3(m, pjoin(prefix, "conv2"), pjoin(prefix, "bn2"), C, C, 1, &rp->c2));
+    return LDM_OK;
+}
+
+static int finalize_module(ldm_module* m) {
+    LDM_REQUIRE(!m->finalized, "module already finalized");
+    const int es = es_of(m->dtype), ck = 128 / es;
+    const int te = m->te;
+    if (m->kind == LDM_MOD_TIME_ADDITION) {
+        const int d = m->in_ch;
+        const std::vector<float>*w1, *b1, *w2, *b2;
+        LDM_TRY(get_param(m, "linear1.weight", (size_t)d * d * 8, &w1));
+        LDM_TRY(get_param(m, "linear1.bias", (size_t)d * 8, &b1));
+        LDM_TRY(get_param(m, "linear2.weight", (size_t)d * 8 * d, &w2));
+        LDM_TRY(get_param(m, "linear2.bias", d, &b2));
+        LDM_TRY(m->pool.upload((void**)&m->tw1, w1->data(), w1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tb1, b1->data(), b1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tw2, w2->data(), w2->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tb2, b2->data(), b2->size() * 4));
+    } else if (m->kind == LDM_MOD_ATTENTION) {
+        LDM_TRY(pack_attention(m, "", m->in_ch, &m->mid_atten));
+    } else if (m->kind == LDM_MOD_RESBLOCK) {
+        const int C = m->in_ch;
+        LDM_REQUIRE(C % 64 == 0, "ResidualBlock channels must be a multiple of 64");
+        LDM_TRY(pack_resblock(m, "", C, &m->rb[0]));
+        const std::vector<float>*wt, *bt;
+        LDM_TRY(get_param(m, "time.weight", (size_t)te * C, &wt));
+        LDM_TRY(get_param(m, "time.bias", C, &bt));
+        LDM_TRY(m->pool.upload((void**)&m->twt, wt->data(), wt->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tbt, bt->data(), bt->size() * 4));
+        m->rb[0].tv_off = 0;
+        m->tv_total = C;
+    } else {
+        const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2], cl = m->in_ch;
+        LDM_REQUIRE(c1 % 64 == 0 && c2 % 64 == 0 && c3 % 64 == 0, "UNet widths must be multiples of 64");
+        m->clp = round_up_i(cl, 64);   // = out_conv's padded width, so z and eps share one NHWC layout
+        (void)ck;
+        // time MLP and the per-block time projections (all f32)
+        const std::vector<float>*w1, *b1, *w2, *b2;
+        LDM_TRY(get_param(m, "time_emb.linear1.weight", (size_t)te * te * 8, &w1));
+        LDM_TRY(get_param(m, "time_emb.linear1.bias", (size_t)te * 8, &b1));
+        LDM_TRY(get_param(m, "time_emb.linear2.weight", (size_t)te * 8 * te, &w2));
+        LDM_TRY(get_param(m, "time_emb.linear2.bias", te, &b2));
+        LDM_TRY(m->pool.upload((void**)&m->tw1, w1->data(), w1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tb1, b1->data(), b1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tw2, w2->data(), w2->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tb2, b2->data(), b2->size() * 4));
+        const int rc[7] = {c1, c2, c3, c3, c3, c2, c1};
+        int tv = 0;
+        for (int i = 0; i < 7; ++i) { m->rb[i].tv_off = tv; tv += rc[i]; }
+        m->tv_total = tv;
+        std::vector<float> wt((size_t)te * tv), bt(tv);
+        for (int i = 0; i < 7; ++i) {
+            const std::vector<float>*w, *b;
+            LDM_TRY(get_param(m, std::string(kResNames[i]) + ".time.weight", (size_t)te * rc[i], &w));
+            LDM_TRY(get_param(m, std::string(kResNames[i]) + ".time.bias", rc[i], &b));
+            for (int k = 0; k < te; ++k)
+                for (int c = 0; c < rc[i]; ++c) wt[(size_t)k * tv + m->rb[i].tv_off + c] = (*w)[(size_t)k * rc[i] + c];
+            for (int c = 0; c < rc[i]; ++c) bt[m->rb[i].tv_off + c] = (*b)[c];
+            LDM_TRY(pack_resblock(m, kResNames[i], rc[i], &m->rb[i]));
+        }
+        LDM_TRY(m->pool.upload((void**)&m->twt, wt.data(), wt.size() * 4));
+        LDM_TRY(m->pool.upload((void**)&m->tbt, bt.data(), bt.size() * 4));
+        LDM_TRY(pack_conv3x3(m, "down1", "", cl, c1, 1, &m->down1, m->clp));
+        LDM_TRY(pack_conv3x3(m, "down2", "", c1, c2, 2, &m->down2));
+        LDM_TRY(pack_conv3x3(m, "down3", "", c2, c3, 2, &m->down3));
+        LDM_TRY(pack_attention(m, "mid_atten", c3, &m->mid_atten));
+        LDM_TRY(pack_convT(m, "up1", c3, c2, &m->up1));
+        LDM_TRY(pack_conv1x1_cat(m, "up_conv1", c2, c2, c2, &m->up_conv1));
+        if (m->scaled) LDM_TRY(pack_attention(m, "up_atten", c2, &m->up_atten));
+        LDM_TRY(pack_convT(m, "up2", c2, c1, &m->up2));
+        LDM_TRY(pack_conv1x1_cat(m, "up_conv2", c1, c1, c1, &m->up_conv2));
+        LDM_TRY(pack_conv3x3(m, "out_conv", "", c1, cl, 1, &m->out_conv));
+        LDM_REQUIRE(m->out_conv.cout == m->clp, "internal: padded output and padded latent widths differ");
+    }
+    m->params.clear();
+    m->finalized = true;
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+struct TimeVec {   // where the per-block time vectors come from
+    const float* table = nullptr;
+    int img_stride = 0, step_stride = 0;
+    const int* step_ptr = nullptr;
+};
+
+static int run_conv(const PackedConv& pc, const void* in0, int cin0, const void* in1, int cin1, void* out, int B, int H,
+                    int W, int act, const void* res, const TimeVec* tv, int tv_off, int out_f32, hipStream_t st) {
+    ConvCall cc;
+    cc.in0 = in0; cc.cin0 = cin0; cc.in1 = in1; cc.cin1 = cin1;
+    cc.out = out; cc.B = B; cc.Hin = H; cc.Win = W;
+    cc.act = act; cc.res = res; cc.out_f32 = out_f32;
+    if (tv) {
+        cc.tvec = tv->table + tv_off;
+        cc.t_img_stride = tv->img_stride;
+        cc.t_step_stride = tv->step_stride;
+        cc.step_ptr = tv->step_ptr;
+    }
+    return launch_tapconv(pc, cc, st);
+}
+
+// ResidualBlock::forward (src/main.rs:372-387): tmp = silu(bn1(conv1(x))) + t ; out = silu(bn2(conv2(tmp)) + x)
+static int run_resblock(const ResBlockP& rp, const void* x, void* tmp, void* out, int B, int H, int W, const TimeVec& tv,
+                        hipStream_t st) {
+    LDM_TRY(run_conv(rp.c1, x, rp.C, nullptr, 0, tmp, B, H, W, ACT_SILU, nullptr, &tv, rp.tv_off, 0, st));
+    LDM_TRY(run_conv(rp.c2, tmp, rp.C, nullptr, 0, out, B, H, W, ACT_SILU, x, nullptr, 0, 0, st));
+    return LDM_OK;
+}
+
+// Attention::forward (src/main.rs:256-276): qkv projection, soft-max attention, out projection + x
+static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, void* att, void* out, int B, int H, int W,
+                         hipStream_t st) {
+    LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(launch_attention(dtype, qkv, att, B, H * W, ap.C, st));
+    LDM_TRY(run_conv(ap.out, att, ap.C, nullptr, 0, out, B, H, W, ACT_NONE, x, nullptr, 0, 0, st));
+    return LDM_OK;
+}
+
+static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_rows, char* base, UnetBufs* ub) {
+    const size_t es = es_of(m->dtype);
+    const size_t p1 = (size_t)B * H * W, p2 = p1 / 4, p3 = p1 / 16;
+    const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    ub->xin = take(p1 * m->clp * es);
+    ub->eps = take(p1 * m->out_conv.cout * 4);
+    ub->a1 = take(p1 * c1 * es); ub->b1 = take(p1 * c1 * es); ub->s1 = take(p1 * c1 * es);
+    ub->a2 = take(p2 * c2 * es); ub->b2 = take(p2 * c2 * es); ub->s2 = take(p2 * c2 * es);
+    ub->a3 = take(p3 * c3 * es); ub->b3 = take(p3 * c3 * es); ub->c3 = take(p3 * c3 * es);
+    ub->qkv3 = take(p3 * 3 * c3 * es); ub->att3 = take(p3 * c3 * es);
+    if (m->scaled) { ub->qkv2 = take(p2 * 3 * c2 * es); ub->att2 = take(p2 * c2 * es); }
+    ub->sinemb = (float*)take((size_t)time_rows * m->te * 4);
+    ub->h1 = (float*)take((size_t)time_rows * m->te * 8 * 4);
+    ub->temb = (float*)take((size_t)time_rows * m->te * 4);
+    ub->tvec = (float*)take((size_t)time_rows * m->tv_total * 4);
+    ub->bytes = off;
+    return off;
+}
+
+// time path: rows of sinusoidal embeddings -> per-block time vectors (src/main.rs:302-306, :377-378)
+static int run_time_path(const ldm_module* m, const float* sinemb, int rows, UnetBufs& ub, hipStream_t st) {
+    LDM_TRY(launch_linear_f32(sinemb, m->tw1, m->tb1, ub.h1, rows, m->te, m->te * 8, ACT_RELU, st));
+    LDM_TRY(launch_linear_f32(ub.h1, m->tw2, m->tb2, ub.temb, rows, m->te * 8, m->te, ACT_NONE, st));
+    LDM_TRY(launch_linear_f32(ub.temb, m->twt, m->tbt, ub.tvec, rows, m->te, m->tv_total, ACT_SILU, st));
+    return LDM_OK;
+}
+
+// Unet::forward body on NHWC buffers (src/main.rs:499-525; pools skipped, dropout = identity).
+// xin [B,H,W,clp]; eps_out [B,H,W,out_conv.cout] f32.
+static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int B, int H, int W,
+                         const TimeVec& tv, hipStream_t st) {
+    const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
+    const int H2 = H / 2, W2 = W / 2, H3 = H / 4, W3 = W / 4;
+    LDM_TRY(run_conv(m->down1, xin, m->clp, nullptr, 0, ub.a1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_resblock(m->rb[0], ub.a1, ub.b1, ub.s1, B, H, W, tv, st));                 // down_1 = s1
+    LDM_TRY(run_conv(m->down2, ub.s1, c1, nullptr, 0, ub.a2, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_resblock(m->rb[1], ub.a2, ub.b2, ub.s2, B, H2, W2, tv, st));               // down_2 = s2
+    LDM_TRY(run_conv(m->down3, ub.s2, c2, nullptr, 0, ub.a3, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_resblock(m->rb[2], ub.a3, ub.b3, ub.c3, B, H3, W3, tv, st));               // down_3 = c3
+    LDM_TRY(run_resblock(m->rb[3], ub.c3, ub.b3, ub.a3, B, H3, W3, tv, st));               // mid_res1 -> a3
+    LDM_TRY(run_attention(m->mid_atten, m->dtype, ub.a3, ub.qkv3, ub.att3, ub.b3, B, H3, W3, st));   // -> b3
+    LDM_TRY(run_resblock(m->rb[4], ub.b3, ub.c3, ub.a3, B, H3, W3, tv, st));               // mid_res2 -> a3
+    LDM_TRY(run_conv(m->up1, ub.a3, c3, nullptr, 0, ub.a2, B, H3, W3, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_resblock(m->rb[5], ub.b2, ub.a2, ub.s2, B, H2, W2, tv, st));               // up_res1 -> s2
+    const void* u1 = ub.s2;
+    if (m->scaled) {
+        LDM_TRY(run_attention(m->up_atten, m->dtype, ub.s2, ub.qkv2, ub.att2, ub.b2, B, H2, W2, st));
+        u1 = ub.b2;
+    }
+    LDM_TRY(run_conv(m->up2, u1, c2, nullptr, 0, ub.a1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_resblock(m->rb[6], ub.b1, ub.a1, ub.s1, B, H, W, tv, st));                 // up_res2 -> s1
+    LDM_TRY(run_conv(m->out_conv, ub.s1, c1, nullptr, 0, eps_out, B, H, W, ACT_NONE, nullptr, nullptr, 0, 1, st));
+    return LDM_OK;
+}
+
+static int ensure_ws(ldm_module* m, size_t bytes) {
+    if (bytes <= m->ws_bytes) return LDM_OK;
+    if (m->ws) {
+        LDM_HIP(hipDeviceSynchronize());
+        LDM_HIP(hipFree(m->ws));
+        m->ws = nullptr;
+        m->ws_bytes = 0;
+    }
+    LDM_HIP(hipMalloc(&m->ws, bytes));
+    m->ws_bytes = bytes;
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler
+// ---------------------------------------------------------------------------------------------
+struct ldm_sampler {
+    ldm_module* unet = nullptr;
+    int T = 0, B = 0, H = 0, W = 0;
+    DevPool pool;
+    UnetBufs ub;
+    float* z = nullptr;       // NHWC f32 state [B,H,W,clp]
+    void* zl = nullptr;       // bf16 copy (bf16 mode)
+    float* coef = nullptr;    // [T][8]
+    int* d_ts = nullptr;      // [T]
+    int* step = nullptr;      // device control words: {step counter, seed low, seed high, chain0}
+    float* noise = nullptr;  // NHWC f32 [steps][B,H,W,clp], allocated on first use
+    size_t noise_bytes = 0;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int g_steps = -1, g_noise = -1;
+    std::vector<float> h_coef;
+    std::vector<int> h_ts;
+    ~ldm_sampler() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (noise) (void)hipFree(noise);
+    }
+};
+
+static int sampler_step(ldm_sampler* s, bool have_noise, unsigned long long seed, unsigned int chain0, float* z_trace,
+                        float* eps_trace, int k, hipStream_t st) {
+    ldm_module* m = s->unet;
+    const int B = s->B, H = s->H, W = s->W;
+    const size_t img = (size_t)B * m->in_ch * H * W;
+    if (z_trace) LDM_TRY(launch_nhwc_to_nchw(s->z, LDM_F32, z_trace + (size_t)k * img, B, m->in_ch, m->clp, H, W, st));
+    TimeVec tv;
+    tv.table = s->ub.tvec; tv.img_stride = 0; tv.step_stride = m->tv_total; tv.step_ptr = s->step;
+    const void* xin = m->dtype == LDM_BF16 ? s->zl : (const void*)s->z;
+    LDM_TRY(run_unet_body(m, s->ub, xin, s->ub.eps, B, H, W, tv, st));
+    if (eps_trace)
+        LDM_TRY(launch_nhwc_to_nchw(s->ub.eps, LDM_F32, eps_trace + (size_t)k * img, B, m->in_ch, m->out_conv.cout, H, W, st));
+    SchedArgs a{};
+    a.z = s->z; a.eps = s->ub.eps; a.eps_dtype = LDM_F32;
+    a.noise = have_noise ? s->noise : nullptr;
+    a.z_lowp = m->dtype == LDM_BF16 ? s->zl : nullptr;
+    a.coef = s->coef; a.step_ptr = s->step;
+    a.n = (long)B * H * W * m->clp;
+    a.pix_per_chain = (long)H * W;
+    a.c4 = m->in_ch / 4; a.cpad4 = m->clp / 4;
+    a.seed = seed; a.chain0 = chain0;
+    a.rng = (const unsigned int*)(s->step + 1);   // device copy, so a captured graph follows later seeds
+    LDM_TRY(launch_sched_step(a, st));
+    LDM_TRY(launch_step_advance(s->step, st));
+    return LDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* ldm_last_error(void) { return g_err.c_str(); }
+int ldm_version(void) { return 1; }
+
+int ldm_get_betas(int num_time, float* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<float> b;
+    host_betas(num_time, b);
+    memcpy(out, b.data(), b.size() * 4);
+    return LDM_OK;
+}
+int ldm_get_alphas(int num_time, float* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<float> a;
+    host_alpha_bars(num_time, a);
+    memcpy(out, a.data(), a.size() * 4);
+    return LDM_OK;
+}
+int ldm_ddpm_coefficients(int num_time, float* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<float> t;
+    host_ddpm_coef(num_time, t);
+    memcpy(out, t.data(), t.size() * 4);
+    return LDM_OK;
+}
+int ldm_ddim_timesteps(int num_time, int steps, int* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<int> ts;
+    LDM_TRY(host_ddim_ts(num_time, steps, ts));
+    memcpy(out, ts.data(), ts.size() * 4);
+    return LDM_OK;
+}
+int ldm_ddim_coefficients(int num_time, int steps, float* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<float> t;
+    LDM_TRY(host_ddim_coef(num_time, steps, t));
+    memcpy(out, t.data(), t.size() * 4);
+    return LDM_OK;
+}
+
+int ldm_sin_time_addition(const int* time_dev, int batch, int dim, float* out_dev, void* stream) {
+    return launch_sin_embed(time_dev, batch, dim, out_dev, (hipStream_t)stream);
+}
+
+int ldm_module_create(ldm_module** out, int kind, int dtype, int in_channels, int time_embed_dim, const int* channels3,
+                      int scaled_attention) {
+    LDM_REQUIRE(out, "null output");
+    LDM_REQUIRE(kind >= LDM_MOD_UNET && kind <= LDM_MOD_TIME_ADDITION, "unknown module kind");
+    LDM_REQUIRE(dtype == LDM_F32 || dtype == LDM_BF16, "unknown dtype");
+    LDM_REQUIRE(in_channels > 0, "channels must be positive");
+    if (kind == LDM_MOD_UNET || kind == LDM_MOD_RESBLOCK)
+        LDM_REQUIRE(time_embed_dim > 0 && time_embed_dim % 4 == 0, "time_embed_dim must be a positive multiple of 4");
+    if (kind == LDM_MOD_UNET) LDM_REQUIRE(in_channels % 4 == 0, "latent channels must be a multiple of 4");
+    int ndev = 0;
+    LDM_HIP(hipGetDeviceCount(&ndev));
+    LDM_REQUIRE(ndev > 0, "no HIP device");
+    std::unique_ptr<ldm_module> m(new ldm_module());
+    m->kind = kind; m->dtype = dtype; m->in_ch = in_channels; m->te = time_embed_dim;
+    if (channels3) for (int i = 0; i < 3; ++i) m->ch[i] = channels3[i];
+    m->scaled = scaled_attention != 0;
+    *out = m.release();
+    return LDM_OK;
+}
+
+int ldm_module_set_param(ldm_module* m, const char* name, const float* host_data, long numel) {
+    LDM_REQUIRE(m && name && host_data && numel > 0, "bad arguments");
+    LDM_REQUIRE(!m->finalized, "module already finalized");
+    m->params[name] = std::vector<float>(host_data, host_data + numel);
+    return LDM_OK;
+}
+
+int ldm_module_finalize(ldm_module* m) {
+    LDM_REQUIRE(m, "null module");
+    return finalize_module(m);
+}
+
+void ldm_module_destroy(ldm_module* m) { delete m; }
+
+int ldm_unet_forward(ldm_module* m, const float* x, const float* time_emb, float* eps, int B, int H, int W, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_UNET && m->finalized, "needs a finalized UNet module");
+    LDM_REQUIRE(x && time_emb && eps, "null tensor");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
+    hipStream_t st = (hipStream_t)stream;
+    UnetBufs ub;
+    const size_t need = plan_unet_bufs(m, B, H, W, B, nullptr, &ub);
+    LDM_TRY(ensure_ws(m, need));
+    plan_unet_bufs(m, B, H, W, B, (char*)m->ws, &ub);
+    LDM_TRY(run_time_path(m, time_emb, B, ub, st));
+    LDM_TRY(launch_nchw_to_nhwc(x, ub.xin, m->dtype, B, m->in_ch, m->clp, H, W, st));
+    TimeVec tv;
+    tv.table = ub.tvec; tv.img_stride = m->tv_total;
+    LDM_TRY(run_unet_body(m, ub, ub.xin, ub.eps, B, H, W, tv, st));
+    LDM_TRY(launch_nhwc_to_nchw(ub.eps, LDM_F32, eps, B, m->in_ch, m->out_conv.cout, H, W, st));
+    return LDM_OK;
+}
+
+int ldm_resblock_forward(ldm_module* m, const float* x, const float* t_emb, float* out, int B, int H, int W, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_RESBLOCK && m->finalized, "needs a finalized ResidualBlock module");
+    LDM_REQUIRE(x && t_emb && out && B > 0 && H > 0 && W > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = es_of(m->dtype), C = m->in_ch;
+    const size_t act = align_up((size_t)B * H * W * C * es, 256);
+    const size_t need = 3 * act + align_up((size_t)B * C * 4, 256);
+    LDM_TRY(ensure_ws(m, need));
+    char* base = (char*)m->ws;
+    void *xin = base, *tmp = base + act, *o = base + 2 * act;
+    float* tvec = (float*)(base + 3 * act);
+    LDM_TRY(launch_linear_f32(t_emb, m->twt, m->tbt, tvec, B, m->te, (int)C, ACT_SILU, st));
+    LDM_TRY(launch_nchw_to_nhwc(x, xin, m->dtype, B, (int)C, (int)C, H, W, st));
+    TimeVec tv;
+    tv.table = tvec; tv.img_stride = (int)C;
+    LDM_TRY(run_resblock(m->rb[0], xin, tmp, o, B, H, W, tv, st));
+    LDM_TRY(launch_nhwc_to_nchw(o, m->dtype, out, B, (int)C, (int)C, H, W, st));
+    return LDM_OK;
+}
+
+int ldm_attention_forward(ldm_module* m, const float* x, float* out, int B, int H, int W, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_ATTENTION && m->finalized, "needs a finalized Attention module");
+    LDM_REQUIRE(x && out && B > 0 && H > 0 && W > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = es_of(m->dtype), C = m->in_ch;
+    const size_t act = align_up((size_t)B * H * W * C * es, 256);
+    LDM_TRY(ensure_ws(m, 6 * act));
+    char* base = (char*)m->ws;
+    void *xin = base, *qkv = base + act, *att = base + 4 * act, *o = base + 5 * act;
+    LDM_TRY(launch_nchw_to_nhwc(x, xin, m->dtype, B, (int)C, (int)C, H, W, st));
+    LDM_TRY(run_attention(m->mid_atten, m->dtype, xin, qkv, att, o, B, H, W, st));
+    LDM_TRY(launch_nhwc_to_nchw(o, m->dtype, out, B, (int)C, (int)C, H, W, st));
+    return LDM_OK;
+}
+
+int ldm_time_addition_forward(ldm_module* m, const float* t, float* out, int B, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_TIME_ADDITION && m->finalized, "needs a finalized TimeAddition module");
+    LDM_REQUIRE(t && out && B > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->in_ch;
+    LDM_TRY(ensure_ws(m, (size_t)B * d * 8 * 4));
+    LDM_TRY(launch_linear_f32(t, m->tw1, m->tb1, (float*)m->ws, B, d, d * 8, ACT_RELU, st));
+    LDM_TRY(launch_linear_f32((const float*)m->ws, m->tw2, m->tb2, out, B, d * 8, d, ACT_NONE, st));
+    return LDM_OK;
+}
+
+int ldm_sched_step(float* z, const float* eps, const float* noise, long n, const float* coef5, int mode, int last,
+                   void* stream) {
+    LDM_REQUIRE(z && eps && coef5 && n > 0 && n % 4 == 0, "bad arguments (n must be a multiple of 4)");
+    LDM_REQUIRE(mode == LDM_DDPM || mode == LDM_DDIM, "unknown mode");
+    LDM_REQUIRE(noise || mode == LDM_DDIM || last, "a DDPM step before the last needs noise");
+    SchedArgs a{};
+    a.z = z; a.eps = eps; a.eps_dtype = LDM_F32; a.noise = noise;
+    for (int i = 0; i < 5; ++i) a.cval[i] = coef5[i];
+    a.cval[5] = (float)mode; a.cval[6] = last ? 1.f : 0.f;
+    a.n = n; a.pix_per_chain = n / 4; a.c4 = 1; a.cpad4 = 1;
+    return launch_sched_step(a, (hipStream_t)stream);
+}
+
+int ldm_philox_normal(float* out, int batch, int C, int H, int W, unsigned long long seed, unsigned int chain0,
+                      unsigned int step, void* stream) {
+    return launch_philox_nchw(out, batch, C, H, W, seed, chain0, step, (hipStream_t)stream);
+}
+
+int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int batch, int H, int W) {
+    LDM_REQUIRE(out, "null output");
+    LDM_REQUIRE(unet && unet->kind == LDM_MOD_UNET && unet->finalized, "needs a finalized UNet module");
+    LDM_REQUIRE(num_time > 0 && batch > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
+    std::unique_ptr<ldm_sampler> s(new ldm_sampler());
+    s->unet = unet; s->T = num_time; s->B = batch; s->H = H; s->W = W;
+    UnetBufs tmp;
+    const size_t need = plan_unet_bufs(unet, batch, H, W, num_time, nullptr, &tmp);
+    void* arena = nullptr;
+    LDM_TRY(s->pool.alloc(&arena, need));
+    LDM_HIP(hipMemset(arena, 0, need));
+    plan_unet_bufs(unet, batch, H, W, num_time, (char*)arena, &s->ub);
+    const size_t nz = (size_t)batch * H * W * unet->clp;
+    LDM_TRY(s->pool.alloc((void**)&s->z, nz * 4));
+    LDM_HIP(hipMemset(s->z, 0, nz * 4));
+    if (unet->dtype == LDM_BF16) {
+        LDM_TRY(s->pool.alloc(&s->zl, nz * 2));
+        LDM_HIP(hipMemset(s->zl, 0, nz * 2));
+    }
+    LDM_TRY(s->pool.alloc((void**)&s->coef, (size_t)num_time * 8 * 4));
+    LDM_TRY(s->pool.alloc((void**)&s->d_ts, (size_t)num_time * 4));
+    LDM_TRY(s->pool.alloc((void**)&s->step, 16));
+    LDM_HIP(hipMemset(s->step, 0, 16));
+    LDM_HIP(hipMemset(s->ub.tvec, 0, (size_t)num_time * unet->tv_total * 4));
+    LDM_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
+    // one eager forward on zeros: validates the shapes and sets every kernel's launch attributes
+    // before anything is captured into a graph
+    TimeVec tv;
+    tv.table = s->ub.tvec; tv.step_stride = unet->tv_total; tv.step_ptr = s->step;
+    const void* xin = unet->dtype == LDM_BF16 ? s->zl : (const void*)s->z;
+    LDM_TRY(run_unet_body(unet, s->ub, xin, s->ub.eps, batch, H, W, tv, nullptr));
+    LDM_HIP(hipDeviceSynchronize());
+    *out = s.release();
+    return LDM_OK;
+}
+
+int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, const float* noise_dev,
+                    unsigned long long seed, unsigned int chain0, float* z_out, float* z_trace, float* eps_trace,
+                    int use_graph, void* stream) {
+    LDM_REQUIRE(s && z_out, "bad arguments");
+    LDM_REQUIRE(mode == LDM_DDPM || mode == LDM_DDIM, "unknown mode");
+    ldm_module* m = s->unet;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, H = s->H, W = s->W, T = s->T;
+    int steps = T;
+    std::vector<float> c5;
+    if (mode == LDM_DDPM) {
+        host_ddpm_coef(T, c5);
+        s->h_ts.resize(T);
+        s->h_coef.assign((size_t)T * 8, 0.f);
+        for (int k = 0; k < T; ++k) {
+            const int i = T - 1 - k;
+            s->h_ts[k] = i;
+            for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)i * 5 + q];
+            s->h_coef[(size_t)k * 8 + 5] = 0.f;
+            s->h_coef[(size_t)k * 8 + 6] = i == 0 ? 1.f : 0.f;
+        }
+    } else {
+        steps = ddim_steps;
+        LDM_TRY(host_ddim_ts(T, steps, s->h_ts));
+        LDM_TRY(host_ddim_coef(T, steps, c5));
+        s->h_coef.assign((size_t)steps * 8, 0.f);
+        for (int k = 0; k < steps; ++k) {
+            for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)k * 5 + q];
+            s->h_coef[(size_t)k * 8 + 5] = 1.f;
+        }
+    }
+    const bool have_noise = noise_dev != nullptr && mode == LDM_DDPM;
+    const size_t nz = (size_t)B * H * W * m->clp;
+    if (have_noise) {
+        const size_t need = (size_t)steps * nz * 4;
+        if (need > s->noise_bytes) {
+            LDM_HIP(hipDeviceSynchronize());
+            if (s->noise) LDM_HIP(hipFree(s->noise));
+            s->noise = nullptr; s->noise_bytes = 0;
+            LDM_HIP(hipMalloc((void**)&s->noise, need));
+            s->noise_bytes = need;
+            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+        }
+    }
+    LDM_HIP(hipMemcpyAsync(s->d_ts, s->h_ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice, st));
+    LDM_HIP(hipMemcpyAsync(s->coef, s->h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice, st));
+    // time path for every visited timestep at once: [steps, tv_total] table (all chains share t)
+    LDM_TRY(launch_sin_embed(s->d_ts, steps, m->te, s->ub.sinemb, st));
+    LDM_TRY(run_time_path(m, s->ub.sinemb, steps, s->ub, st));
+    if (z0) {
+        LDM_TRY(launch_nchw_to_nhwc(z0, s->z, LDM_F32, B, m->in_ch, m->clp, H, W, st));
+        if (m->dtype == LDM_BF16) LDM_TRY(launch_cast_f32_to_bf16(s->z, s->zl, (long)nz, st));
+    } else {
+        LDM_TRY(launch_philox_init(s->z, m->dtype == LDM_BF16 ? s->zl : nullptr, (long)nz, (long)H * W, m->in_ch / 4,
+                                   m->clp / 4, seed, chain0, 0xFFFFFFFFu, st));
+    }
+    if (have_noise) {
+        const int per = 32768 / B > 0 ? 32768 / B : 1;   // steps per launch (grid.z limit)
+        const size_t img = (size_t)B * m->in_ch * H * W;
+        for (int k0 = 0; k0 < steps; k0 += per) {
+            const int kn = steps - k0 < per ? steps - k0 : per;
+            LDM_TRY(launch_nchw_to_nhwc(noise_dev + (size_t)k0 * img, s->noise + (size_t)k0 * nz, LDM_F32, kn * B,
+                                        m->in_ch, m->clp, H, W, st));
+        }
+    }
+    LDM_TRY(launch_set_ctl(s->step, seed, chain0, st));
+    const bool tracing = z_trace || eps_trace;
+    if (use_graph && !tracing) {
+        if (!s->exec || s->g_steps != steps || s->g_noise != (int)have_noise) {
+            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            LDM_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeRelaxed));
+            int rc = LDM_OK;
+            for (int k = 0; k < steps && rc == LDM_OK; ++k)
+                rc = sampler_step(s, have_noise, seed, chain0, nullptr, nullptr, k, s->cap_stream);
+            hipError_t e = hipStreamEndCapture(s->cap_stream, &graph);
+            if (rc != LDM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            LDM_HIP(e);
+            e = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            LDM_HIP(e);
+            s->g_steps = steps; s->g_noise = (int)have_noise;
+        }
+        LDM_HIP(hipGraphLaunch(s->exec, st));
+    } else {
+        for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, have_noise, seed, chain0, z_trace, eps_trace, k, st));
+    }
+    LDM_TRY(launch_nhwc_to_nchw(s->z, LDM_F32, z_out, B, m->in_ch, m->clp, H, W, st));
+    return LDM_OK;
+}
+
+void ldm_sampler_destroy(ldm_sampler* s) { delete s; }
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+/* C ABI of libldm_hip.so: the MI355X (gfx950) implementation of the latent-diffusion sampling hot
+ * path of ragu812/diffusionModel -- UNet forward, timestep embedding, DDPM/DDIM scheduler step and
+ * the sampling loop.  Plain pointers and sizes only; every `*_dev` pointer is device memory of the
+ * current HIP device, `stream` is a hipStream_t (NULL = default stream).  Every function returns
+ * LDM_OK or an error code; ldm_last_error() gives the text for the calling thread.
+ *
+ * Tensor conventions at this boundary are the reference's: activations NCHW f32, Conv2d weights
+ * [Cout,Cin,kh,kw], ConvTranspose2d weights [Cin,Cout,kh,kw], Linear weights [d_in,d_out]
+ * (burn's layouts).  Internally activations are NHWC bf16 or f32.
+ *
+ * Deviations from the reference as written (it cannot run as written):
+ *  - down-sampling uses the stride-2 convolutions down2/down3; pool1/pool2 (src/main.rs:432,443,
+ *    502,506) are skipped, which is the only shape-consistent reading of Unet::forward;
+ *  - inference semantics: BatchNorm uses running statistics (folded into the preceding conv,
+ *    eps 1e-5), Dropout is the identity;
+ *  - the per-step NaN probes of denoising_process (src/main.rs:706-710,725-729,759-763) are host
+ *    synchronisations and are not reproduced.
+ */
+#ifndef LDM_HIP_H
+#define LDM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LDM_OK = 0, LDM_ERR_INVALID = 1, LDM_ERR_HIP = 2, LDM_ERR_STATE = 3 };
+enum { LDM_F32 = 0, LDM_BF16 = 1 };                 /* arithmetic type of weights and activations */
+enum { LDM_DDPM = 0, LDM_DDIM = 1 };
+enum { LDM_MOD_UNET = 0, LDM_MOD_RESBLOCK = 1, LDM_MOD_ATTENTION = 2, LDM_MOD_TIME_ADDITION = 3 };
+
+typedef struct ldm_module ldm_module;
+typedef struct ldm_sampler ldm_sampler;
+
+const char* ldm_last_error(void);
+int ldm_version(void);
+
+/* ---- noise schedule (host, f32, operation order of the reference) ------------------------- */
+/* DiffusionModel::get_betas, src/main.rs:553-567: linear 1e-4 -> 0.02 clamped to [1e-6, 0.999]. */
+int ldm_get_betas(int num_time, float* out_host);
+/* DiffusionModel::get_alphas, src/main.rs:569-583: returns the running product alpha-bar. */
+int ldm_get_alphas(int num_time, float* out_host);
+/* Scalars of the reverse step, src/main.rs:712-747; row i = {sqrt(abar_i), sqrt(1-abar_i), coef1,
+ * coef2, sigma}; row 0 = {.., .., 1, 0, 0} (the reference sets z = x0 there, :765). */
+int ldm_ddpm_coefficients(int num_time, float* out_host /* [num_time][5] */);
+/* DDIM (eta = 0) has no counterpart in the reference.  Timesteps t_k = k * (num_time / steps),
+ * visited from k = steps-1 down to 0; row k (visit order) = {sqrt(abar_t), sqrt(1-abar_t),
+ * sqrt(abar_prev), sqrt(1-abar_prev), 0}, abar_prev = abar[t - num_time/steps] or 1 below zero. */
+int ldm_ddim_timesteps(int num_time, int steps, int* out_host /* [steps] */);
+int ldm_ddim_coefficients(int num_time, int steps, float* out_host /* [steps][5] */);
+
+/* ---- sin_time_addition, src/main.rs:309-335 ------------------------------------------------- */
+/* out[b, i] = sin(t_b f_i), out[b, dim/2 + i] = cos(t_b f_i), f_i = exp(-(i * 4 ln10 / (dim/2))). */
+int ldm_sin_time_addition(const int* time_dev, int batch, int dim, float* out_dev, void* stream);
+
+/* ---- modules ------------------------------------------------------------------------------ */
+/* kind LDM_MOD_UNET:          Unet::new(in_channels, time_embed_dim), src/main.rs:417-494;
+ *                             channels3 = {64,128,256} when NULL; scaled_attention adds one
+ *                             Attention(channels3[1]) after up_res1 (named "up_atten").
+ * kind LDM_MOD_RESBLOCK:      ResidualBlock::new(channels = in_channels, time_embed_dim), :346-370
+ * kind LDM_MOD_ATTENTION:     Attention::new(channels = in_channels), :247-255
+ * kind LDM_MOD_TIME_ADDITION: TimeAddition::new(dim = in_channels), :285-300
+ * Parameters are set by their Rust field path ("down_res1.conv1.weight", "mid_atten.question.bias",
+ * "down_res1.bn1.running_var", "time_emb.linear1.weight"; for the single-block kinds without the
+ * block prefix: "conv1.weight", "question.weight", "linear1.weight") from host f32 arrays, then
+ * ldm_module_finalize folds BatchNorm, packs for the kernels and uploads. */
+int ldm_module_create(ldm_module** out, int kind, int dtype, int in_channels, int time_embed_dim,
+                      const int* channels3, int scaled_attention);
+int ldm_module_set_param(ldm_module* m, const char* name, const float* host_data, long numel);
+int ldm_module_finalize(ldm_module* m);
+void ldm_module_destroy(ldm_module* m);
+
+/* Unet::forward(x, time), src/main.rs:496-526.  x [B,in_channels,H,W], time_emb [B,time_embed_dim]
+ * (the sinusoidal embedding), eps [B,in_channels,H,W]; H and W multiples of 4. */
+int ldm_unet_forward(ldm_module* m, const float* x_dev, const float* time_emb_dev, float* eps_dev,
+                     int B, int H, int W, void* stream);
+/* ResidualBlock::forward(x, t_emb), src/main.rs:372-387.  x/out [B,channels,H,W], t_emb [B,time_embed_dim]. */
+int ldm_resblock_forward(ldm_module* m, const float* x_dev, const float* t_emb_dev, float* out_dev,
+                         int B, int H, int W, void* stream);
+/* Attention::forward(x), src/main.rs:256-276.  x/out [B,channels,H,W]. */
+int ldm_attention_forward(ldm_module* m, const float* x_dev, float* out_dev, int B, int H, int W, void* stream);
+/* TimeAddition::forward(t), src/main.rs:302-306.  t/out [B,dim]. */
+int ldm_time_addition_forward(ldm_module* m, const float* t_dev, float* out_dev, int B, void* stream);
+
+/* ---- one scheduler update on flat f32 arrays, src/main.rs:712-756,765 --------------------- */
+/* coef5 = one row of ldm_ddpm_coefficients / ldm_ddim_coefficients.  DDPM: z <- (x0*c1 + z*c2) +
+ * sigma*noise, or x0 when `last`; DDIM: z <- x0*c1 + eps*c2; x0 = (z - eps*s1m)/sa.  noise_dev may be
+ * NULL for DDIM and for the last DDPM step. */
+int ldm_sched_step(float* z_dev, const float* eps_dev, const float* noise_dev, long n, const float* coef5,
+                   int mode, int last, void* stream);
+
+/* ---- the sampling loop: DiffusionModel::denoising_process, src/main.rs:681-777 ------------ */
+/* The loop runs on `batch` independent chains of shape [in_channels,H,W]; the trailing vae.decode
+ * (:786) is outside this library.  All per-call memory is allocated by ldm_sampler_create. */
+int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int batch, int H, int W);
+/* mode LDM_DDPM visits i = num_time-1 .. 0; LDM_DDIM visits ddim_steps strided timesteps.
+ * z0_dev   [batch,C,H,W] initial latent, or NULL: drawn from the counter-based generator.
+ * noise_dev [steps,batch,C,H,W] per-step Gaussian noise (DDPM), or NULL: counter-based generator
+ *          keyed by (seed, chain0 + chain index, step, element) -- independent of how chains are
+ *          split over processes.
+ * z_out_dev [batch,C,H,W].  z_trace_dev / eps_trace_dev: optional [steps,batch,C,H,W] records of
+ *          each step's input latent and predicted noise (forces eager launches).
+ * use_graph: replay the whole loop from one captured hipGraph (captured on first use). */
+int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0_dev, const float* noise_dev,
+                    unsigned long long seed, unsigned int chain0, float* z_out_dev, float* z_trace_dev,
+                    float* eps_trace_dev, int use_graph, void* stream);
+void ldm_sampler_destroy(ldm_sampler* s);
+
+/* Standard-normal field of the counter-based generator, [batch,C,H,W] f32 (C multiple of 4):
+ * what ldm_sampler_run draws at `step` (0xFFFFFFFF = the initial latent). */
+int ldm_philox_normal(float* out_dev, int batch, int C, int H, int W, unsigned long long seed,
+                      unsigned int chain0, unsigned int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_HIP_H */

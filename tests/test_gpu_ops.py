@@ -1,0 +1,148 @@
+"""GPU parity of every operator of the hot path against the CPU restatement (oracle/), through the
+C ABI.  f32: relative L2 error <= 1e-4; bf16: <= 2e-2 (tests/util.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import TOL, max_err, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ldm_oracle
+    return ldm_oracle
+
+
+@pytest.fixture(scope="module")
+def A():
+    import diffusionmodel_amd
+    return diffusionmodel_amd
+
+
+def _say(msg):
+    print(msg, flush=True)
+
+
+# ---- schedule + scheduler step ------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["ddpm", "ddim"])
+def test_sched_step(A, O, mode):
+    torch.manual_seed(0)
+    T = 50
+    z = torch.randn(3, 8, 6, 10)
+    eps = torch.randn_like(z)
+    noise = torch.randn_like(z)
+    coef = O.ddpm_coefficients(T) if mode == "ddpm" else O.ddim_coefficients(1000, 50)
+    for i in (49, 17, 1, 0):
+        if mode == "ddpm":
+            ref = O.ddpm_step(z, eps, i, coef, noise)
+        else:
+            ref = O.ddim_step(z, eps, i, coef)
+        got = A.sched_step(z.cuda().clone(), eps.cuda(), coef[i], mode, last=(mode == "ddpm" and i == 0),
+                           noise=noise.cuda())
+        _say(f"sched {mode} i={i} max_err={max_err(got, ref):.3e}")
+        # same f32 operation order on both sides: equal up to the rounding of the division
+        assert rel_err(got, ref) < 1e-6
+
+
+def test_sin_time_addition(A, O):
+    t = torch.tensor([0, 1, 49, 999, 500], dtype=torch.int64)
+    ref = O.sin_time_addition(t, 256)
+    got = A.sin_time_addition(t.cuda(), 256)
+    _say(f"sin_time_addition max_err={max_err(got, ref):.3e}")
+    assert max_err(got, ref) < 2e-4      # sin/cos of arguments up to 999 in f32
+    ref64 = O.sin_time_addition(t, 256, dtype=torch.float64)
+    assert max_err(got, ref64) < 2e-4
+
+
+def test_time_addition(A, O):
+    from diffusionmodel_amd.weights import synthetic_from_shapes, time_addition_param_shapes
+    w = synthetic_from_shapes(time_addition_param_shapes(256), 3)
+    t = O.sin_time_addition(torch.tensor([3, 40, 7]), 256)
+    ref = O.time_addition({"m." + k: v for k, v in w.items()}, "m", t)
+    got = A.TimeAddition(256, weights=w)(t.cuda())
+    _say(f"time_addition rel_err={rel_err(got, ref):.3e}")
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_philox_normal(A, O):
+    ref = O.philox_normal_nchw(1234, 5, 7, 2, 64, 4, 4)
+    got = A.philox_normal(2, 64, 4, 4, seed=1234, chain0=5, step=7)
+    _say(f"philox max_err={max_err(got, ref):.3e} mean={got.mean().item():.3f} std={got.std().item():.3f}")
+    assert max_err(got, ref) < 1e-4
+    big = A.philox_normal(4, 64, 32, 32, seed=9)
+    assert abs(big.mean().item()) < 0.01 and abs(big.std().item() - 1.0) < 0.01
+
+
+# ---- ResidualBlock (conv3x3 + folded BN + SiLU + time add + residual) ---------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 8, 8), (128, 2, 4, 4), (64, 1, 20, 36), (256, 3, 16, 16), (64, 2, 64, 64)])
+def test_resblock(A, O, dtype, C, B, H, W):
+    from diffusionmodel_amd.weights import resblock_param_shapes, synthetic_from_shapes
+    w = synthetic_from_shapes(resblock_param_shapes(C, 256), 11)
+    torch.manual_seed(1)
+    x = torch.randn(B, C, H, W)
+    t = torch.randn(B, 256)
+    ref = O.residual_block({"m." + k: v for k, v in w.items()}, "m", x, t)
+    _say(f"resblock {dtype} C={C} {B}x{H}x{W}")
+    got = A.ResiduelBlock(C, 256, dtype=dtype, weights=w)(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < TOL[dtype]
+
+
+# ---- Attention ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,B,H,W", [(256, 2, 4, 4), (256, 2, 16, 16), (128, 1, 12, 20), (256, 1, 1, 1), (512, 1, 8, 8)])
+def test_attention(A, O, dtype, C, B, H, W):
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    w = synthetic_from_shapes(attention_param_shapes(C), 5)
+    torch.manual_seed(2)
+    x = torch.randn(B, C, H, W) * 2.0      # larger scores -> a soft-max that is not flat
+    ref = O.attention({"m." + k: v for k, v in w.items()}, "m", x)
+    _say(f"attention {dtype} C={C} {B}x{H}x{W}")
+    got = A.Attention(C, dtype=dtype, weights=w)(x.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    e_branch = rel_err(got - x.cuda(), ref - x)      # without the residual, which dominates the norm
+    _say(f"  rel_err={e:.3e} branch={e_branch:.3e}")
+    assert e < TOL[dtype]
+    assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
+
+
+# ---- full UNet forward --------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("Cl,B,S", [(64, 4, 4), (64, 2, 16), (8, 2, 8), (64, 1, 64)])
+def test_unet_forward(A, O, dtype, Cl, B, S):
+    cfg = A.LDMConfig(in_channels=Cl)
+    w = A.make_synthetic_weights(cfg, 0)
+    torch.manual_seed(3)
+    x = torch.randn(B, Cl, S, S)
+    te = O.sin_time_addition(torch.tensor([7, 31, 0, 49][:B]), 256)
+    ref = O.unet_forward(w, x, te)
+    _say(f"unet {dtype} Cl={Cl} B={B} S={S}")
+    net = A.UNet(Cl, 256, dtype=dtype, weights=w)
+    got = net(x.cuda(), te.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_unet_scaled(A, O, dtype):
+    cfg = A.LDMConfig.scaled()
+    w = A.make_synthetic_weights(cfg, 0)
+    torch.manual_seed(4)
+    x = torch.randn(1, 64, 16, 16)
+    te = O.sin_time_addition(torch.tensor([900]), 256)
+    ref = O.unet_forward(w, x, te, scaled_attention=True)
+    _say(f"unet scaled {dtype}")
+    net = A.UNet(64, 256, channels=cfg.channels, scaled_attention=True, dtype=dtype, weights=w)
+    got = net(x.cuda(), te.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < TOL[dtype]

@@ -1,0 +1,74 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/ldm_hip.h declares, the host
+schedule equals the CPU restatement bit for bit, parameter inventory, argument validation."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffusionmodel_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ldm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(ldm_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/ldm_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.ldm_version() == 1
+
+
+@pytest.mark.parametrize("T", [1, 2, 50, 150, 1000, 1200])
+def test_schedule_bit_exact_with_oracle(T):
+    from diffusionmodel_amd import schedule
+    from oracle import ldm_oracle as O
+    assert np.array_equal(schedule.get_betas(T), O.get_betas(T))
+    assert np.array_equal(schedule.get_alphas(T), O.get_alphas(T))
+    assert np.array_equal(schedule.ddpm_coefficients(T), O.ddpm_coefficients(T))
+    for steps in sorted({1, min(T, 7), min(T, 50)}):
+        assert schedule.ddim_timesteps(T, steps) == O.ddim_timesteps(T, steps)
+        assert np.array_equal(schedule.ddim_coefficients(T, steps), O.ddim_coefficients(T, steps))
+
+
+def test_schedule_rejects_bad_arguments():
+    from diffusionmodel_amd import _lib, schedule
+    with pytest.raises(_lib.LdmError):
+        schedule.ddim_timesteps(50, 51)
+    with pytest.raises(_lib.LdmError):
+        schedule.ddim_coefficients(50, 0)
+
+
+def test_param_inventory():
+    from diffusionmodel_amd import LDMConfig, make_synthetic_weights, unet_param_shapes
+    shapes = unet_param_shapes(LDMConfig())
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    # 7.04 M parameters incl. BatchNorm running statistics (default UNet, latent 64)
+    assert 7_000_000 < n < 7_100_000
+    assert shapes["up1.weight"] == (256, 128, 4, 4)            # ConvTranspose2d [Cin,Cout,kh,kw]
+    assert shapes["up_conv1.weight"] == (128, 256, 1, 1)
+    assert shapes["mid_atten.question.weight"] == (256, 256)
+    assert shapes["time_emb.linear1.weight"] == (256, 2048)     # Linear [d_in,d_out]
+    w = make_synthetic_weights(LDMConfig(), 0)
+    w2 = make_synthetic_weights(LDMConfig(), 0)
+    assert all(torch.equal(w[k], w2[k]) for k in w)
+    assert (w["down_res1.bn1.running_var"] > 0).all()
+    sc = unet_param_shapes(LDMConfig.scaled())
+    assert "up_atten.key.weight" in sc and sc["down3.weight"] == (512, 256, 3, 3)
+
+
+def test_chain_range_partitions_the_batch():
+    from diffusionmodel_amd import chain_range
+    for gb in (1, 7, 64, 512):
+        for world in (1, 2, 3, 8):
+            r = [chain_range(gb, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == gb
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        chain_range(8, 2, 2)
