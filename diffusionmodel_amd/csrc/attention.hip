@@ -26,6 +26,8 @@ __device__ __forceinline__ void at_glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// by-value helper: bit_cast applied directly to a vector-element expression reads element 0
+__device__ __forceinline__ float at_u2f(unsigned int u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned int at_pack2(float a, float b) {
     return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)a) |
            ((unsigned int)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
@@ -122,8 +124,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             sacc[kf][qf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __builtin_bit_cast(float, kfrag[e]), __builtin_bit_cast(float, qreg[qf][ks][e]),
-                                sacc[kf][qf], 0, 0, 0);
+                                at_u2f(kfrag[e]), at_u2f(qreg[qf][ks][e]), sacc[kf][qf], 0, 0, 0);
                     }
                 }
             }

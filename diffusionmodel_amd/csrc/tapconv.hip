@@ -62,6 +62,9 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, (unsigned int)h << 16);
 }
 
+// by-value helper: bit_cast applied directly to a vector-element expression reads element 0
+__device__ __forceinline__ float u2f(unsigned int u) { return __builtin_bit_cast(float, u); }
+
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -191,8 +194,7 @@ __global__ __launch_bounds__(256, MINW) void tapconv_kernel(const TapConvArgs a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __builtin_bit_cast(float, wf[nf][q]), __builtin_bit_cast(float, xf[mf][q]), acc[nf][mf],
-                                0, 0, 0);
+                                u2f(wf[nf][q]), u2f(xf[mf][q]), acc[nf][mf], 0, 0, 0);
                     }
                 }
         }
