@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of a 50-step DDIM chain through the UNet on MI355X.
+
+One "step" of this benchmark = one whole sampling call: 50 DDIM steps (strided over num_time = 1000)
+of the default UNet (channels 64/128/256, latent 64) on a batch of 64 latents of 64x64 per GPU, bf16
+activations/weights with f32 accumulation and f32 latent state, the whole loop replayed from one
+hipGraph.  Inputs are synthetic and already resident in HBM; the VAE decode is outside the path.
+With N > 1 ranks every rank denoises its own 64 chains (weak scaling) and one all-gather collects
+the final latents inside the timed region.
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline     -- the dominant kernel (3x3 tap convolution 64->64 channels on [64,64,64,64]) timed
+                  alone with HIP events on the launch stream: algorithmic FLOPs / average duration
+                  against the dense bf16 MFMA peak of 2.5 PFLOP/s;
+  cpu_baseline -- the CPU restatement of the reference's Rust path (oracle/, torch CPU f32) timed on
+                  the host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak of MI355X
+PEAK_F32_TFLOPS = 157.3
+UNET_FLOP_PER_SAMPLE_S64 = 6.009e9   # default UNet at 64x64 latents, 2 * MACs of all contractions
+
+
+def unet_flops(cfg_channels, cl, S, scaled, te=256):
+    """2 * MACs of the UNet per sample (biases/activations excluded)."""
+    c1, c2, c3 = cfg_channels
+    P1, P2, P3 = S * S, S * S // 4, S * S // 16
+    res = lambda C, P: 2 * 9 * C * C * P + te * C            # noqa: E731
+    att = lambda C, P: 4 * C * C * P + 2 * P * P * C          # noqa: E731
+    mac = 2 * 8 * te * te
+    mac += 9 * cl * c1 * P1 + res(c1, P1)
+    mac += 9 * c1 * c2 * P2 + res(c2, P2)
+    mac += 9 * c2 * c3 * P3 + res(c3, P3)
+    mac += res(c3, P3) * 2 + att(c3, P3)
+    mac += 4 * c3 * c2 * P2 + 2 * c2 * c2 * P2 + res(c2, P2)
+    if scaled:
+        mac += att(c2, P2)
+    mac += 4 * c2 * c1 * P1 + 2 * c1 * c1 * P1 + res(c1, P1)
+    mac += 9 * c1 * cl * P1
+    return 2.0 * mac
+
+
+def time_dominant_kernel(A, dtype, B, S, C, iters=30):
+    """Average duration (ms) of the 3x3 tap convolution C->C on [B,S,S,C], HIP events on the launch stream."""
+    from diffusionmodel_amd.ops import ConvOp
+    g = torch.Generator().manual_seed(0)
+    w = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1) * (3.0 / (9 * C)) ** 0.5
+    b = torch.randn(C, generator=g) * 0.05
+    op = ConvOp("conv3x3", w, b, dtype=dtype)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    x = torch.randn(B, S, S, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).to(td)
+    out = torch.empty_like(x)
+    for _ in range(5):
+        op(x, out=out)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        op(x, out=out)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flop = 2.0 * B * S * S * C * C * 9
+    return ms, flop
+
+
+def cpu_baseline(steps_sample=5):
+    """CPU restatement (oracle) on the host: config 1 = 50-step DDPM, B = 4, 64x64 latents, f32."""
+    from oracle import ldm_oracle as O
+    import diffusionmodel_amd as A
+    cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    B, S, T = 4, 64, 50
+    z = torch.randn(B, 64, S, S, generator=torch.Generator().manual_seed(1234))
+    coef = O.ddpm_coefficients(T)
+    noise = torch.randn(B, 64, S, S, generator=torch.Generator().manual_seed(4321))
+    with torch.no_grad():
+        te = O.sin_time_addition(torch.full((B,), T - 1), 256)
+        O.unet_forward(w, z, te)                               # warm-up
+        t0 = time.perf_counter()
+        for k in range(steps_sample):
+            t = T - 1 - k
+            te = O.sin_time_addition(torch.full((B,), t), 256)
+            eps = O.unet_forward(w, z, te)
+            z = O.ddpm_step(z, eps, t, coef, noise)
+        dt = (time.perf_counter() - t0) / steps_sample
+    return {"value": B / (T * dt), "unit": "images/s", "cores": cores, "kind": "port",
+            "unet_steps_per_sec": 1.0 / dt,
+            "sample": f"{steps_sample} of 50 DDPM steps, B=4, [4,64,64,64] f32, torch CPU restatement of src/main.rs "
+                      f"(not the reference binary), {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
+    ap.add_argument("--spatial", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--sampler", default="ddim", choices=["ddim", "ddpm"])
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--num-time", type=int, default=1000)
+    ap.add_argument("--scaled", action="store_true", help="scaled UNet (128/256/512, attention at 2 resolutions)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import diffusionmodel_amd as A
+    cfg = A.LDMConfig.scaled() if args.scaled else A.LDMConfig()
+    weights = A.make_synthetic_weights(cfg, 0)
+    num_time = args.num_time if args.sampler == "ddim" else args.ddim_steps
+    model = A.DiffusionModel(cfg.in_channels, 3, num_time, cfg.time_embed_dim, cfg.channels, cfg.scaled_attention,
+                             dtype=args.dtype, weights=weights)
+    B, S = args.batch, args.spatial
+    global_batch = B * world
+    chain0 = rank * B
+    z0 = torch.randn(B, cfg.in_channels, S, S, device="cuda",
+                     generator=torch.Generator(device="cuda").manual_seed(1234 + rank))
+    n_unet_steps = args.ddim_steps
+
+    def one_call():
+        if args.sampler == "ddim":
+            z = model.ddim_sample(B, args.ddim_steps, spatial=S, z0=z0, chain0=chain0, use_graph=not args.no_graph)
+        else:
+            z = model.denoising_process(B, spatial=S, z0=z0, seed=7, chain0=chain0, use_graph=not args.no_graph)
+        if world > 1:
+            z = A.gather_latents(z, global_batch)
+        return z
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_call()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_call()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite latents"
+    assert out.shape[0] == global_batch
+
+    images_per_s = global_batch * args.steps / dt
+    unet_steps_per_s = args.steps * n_unet_steps / dt           # per GPU (all ranks step in lock-step)
+    flop_step = unet_flops(cfg.channels, cfg.in_channels, S, cfg.scaled_attention) * B
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+
+    if rank == 0:
+        c_dom = cfg.channels[0]
+        kms, kflop = time_dominant_kernel(A, args.dtype, B, S, c_dom)
+        achieved = kflop / (kms * 1e-3) / 1e12
+        res = {
+            "metric": "images/sec (50-step DDIM)" if args.sampler == "ddim" else f"images/sec ({n_unet_steps}-step DDPM)",
+            "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{n_unet_steps}-step {args.sampler.upper()} over num_time={num_time}, "
+                                   f"{'scaled' if args.scaled else 'default'} UNet {list(cfg.channels)}, latent "
+                                   f"[{B},{cfg.in_channels},{S},{S}] per GPU, hipGraph={not args.no_graph}",
+                       "global_batch": global_batch, "per_gpu_batch": B, "spatial": S,
+                       "parallelism": f"dp{world} (batch-sharded chains, one all-gather of final latents)"},
+            "unet_steps_per_sec": unet_steps_per_s,
+            "unet_tflops": flop_step * unet_steps_per_s / 1e12,
+            "unet_frac_of_mfma_peak": flop_step * unet_steps_per_s / 1e12 / peak,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": f"tapconv 3x3 {c_dom}->{c_dom} on [{B},{S},{S},{c_dom}] {args.dtype}",
+                         "avg_ms": kms, "flop_per_launch": kflop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,9 @@ SIGNATURES = {
     "ldm_resblock_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_time_addition_forward": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "ldm_conv_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldm_conv_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldm_conv_destroy": (None, [_vp]),
     "ldm_sched_step": (_i, [_vp, _vp, _vp, _l, _fp, _i, _i, _vp]),
     "ldm_sampler_create": (_i, [C.POINTER(_vp), _vp, _i, _i, _i, _i]),
     "ldm_sampler_run": (_i, [_vp, _i, _i, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _i, _vp]),

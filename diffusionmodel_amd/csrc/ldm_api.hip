@@ -231,6 +231,12 @@ struct ldm_module {
     ~ldm_module() { if (ws) (void)hipFree(ws); }
 };
 
+struct ldm_conv {
+    PackedConv pc;
+    DevPool pool;
+    int cin0 = 0, cin1 = 0;
+};
+
 static const char* kResNames[7] = {"down_res1", "down_res2", "down_res3", "mid_res1", "mid_res2", "up_res1", "up_res2"};
 
 static int es_of(int dtype) { return dtype == LDM_BF16 ? 2 : 4; }
@@ -747,6 +753,50 @@ int ldm_time_addition_forward(ldm_module* m, const float* t, float* out, int B, 
     LDM_TRY(launch_linear_f32((const float*)m->ws, m->tw2, m->tb2, out, B, d * 8, d, ACT_NONE, st));
     return LDM_OK;
 }
+
+int ldm_conv_create(ldm_conv** out, int kind, int dtype, int cin0, int cin1, int cout, const float* w, const float* b) {
+    LDM_REQUIRE(out && w && b, "null argument");
+    LDM_REQUIRE(kind >= CONV3x3_S1 && kind <= CONV1x1, "unknown conv kind");
+    LDM_REQUIRE(dtype == LDM_F32 || dtype == LDM_BF16, "unknown dtype");
+    LDM_REQUIRE(cin0 > 0 && cin0 % 64 == 0 && cin1 >= 0 && cin1 % 64 == 0 && cout > 0 && cout % 64 == 0,
+                "channel counts must be multiples of 64");
+    LDM_REQUIRE(cin1 == 0 || kind == CONV1x1, "only conv1x1 takes a second source");
+    int ndev = 0;
+    LDM_HIP(hipGetDeviceCount(&ndev));
+    LDM_REQUIRE(ndev > 0, "no HIP device");
+    std::unique_ptr<ldm_conv> c(new ldm_conv());
+    c->cin0 = cin0; c->cin1 = cin1;
+    const int cin = cin0 + cin1;
+    PackSpec sp;
+    sp.kind = kind; sp.dtype = dtype; sp.cout = cout;
+    sp.src = {cin0};
+    if (cin1) sp.src.push_back(cin1);
+    if (kind == CONV3x3_S1 || kind == CONV3x3_S2)
+        sp.w = [=](int, int tap, int co, int ci) { return w[((size_t)co * cin + ci) * 9 + tap]; };
+    else if (kind == CONVT4x4_S2)
+        sp.w = [=](int ph, int tap, int co, int ci) {
+            const int ky = 3 - (ph >> 1) - 2 * (tap >> 1), kx = 3 - (ph & 1) - 2 * (tap & 1);
+            return w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+        };
+    else
+        sp.w = [=](int, int, int co, int ci) { return w[(size_t)co * cin + ci]; };
+    sp.bias = [=](int co) { return b[co]; };
+    LDM_TRY(pack_conv(sp, c->pool, &c->pc, nullptr));
+    *out = c.release();
+    return LDM_OK;
+}
+
+int ldm_conv_forward(ldm_conv* c, const void* in0, const void* in1, const void* res, void* out, int B, int Hin, int Win,
+                     int act, void* stream) {
+    LDM_REQUIRE(c && in0 && out, "null argument");
+    LDM_REQUIRE(act >= ACT_NONE && act <= ACT_RELU, "unknown activation");
+    ConvCall cc;
+    cc.in0 = in0; cc.cin0 = c->cin0; cc.in1 = in1; cc.cin1 = c->cin1;
+    cc.res = res; cc.out = out; cc.B = B; cc.Hin = Hin; cc.Win = Win; cc.act = act;
+    return launch_tapconv(c->pc, cc, (hipStream_t)stream);
+}
+
+void ldm_conv_destroy(ldm_conv* c) { delete c; }
 
 int ldm_sched_step(float* z, const float* eps, const float* noise, long n, const float* coef5, int mode, int last,
                    void* stream) {

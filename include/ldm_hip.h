@@ -81,6 +81,21 @@ int ldm_attention_forward(ldm_module* m, const float* x_dev, float* out_dev, int
 /* TimeAddition::forward(t), src/main.rs:302-306.  t/out [B,dim]. */
 int ldm_time_addition_forward(ldm_module* m, const float* t_dev, float* out_dev, int B, void* stream);
 
+/* ---- one convolution on NHWC tensors in the library's own layout (kernel-level operator) --- */
+/* The burn layers behind it: Conv2d 3x3 stride 1 / stride 2 padding 1 (src/main.rs:348-366,423-452,
+ * 486-492), ConvTranspose2d 4x4 stride 2 padding 1 (:460-480), Conv2d 1x1 on a channel concatenation
+ * of two sources (:468-483 with the cat at :516,521).  kind: 0 conv3x3/s1, 1 conv3x3/s2,
+ * 2 convT4x4/s2, 3 conv1x1.  weight_host: [cout,cin,3,3] | [cin,cout,4,4] | [cout,cin0+cin1]; bias [cout].
+ * Tensors are NHWC device arrays of `dtype` elements (bf16 or f32): in0 [B,H,W,cin0], in1 [B,H,W,cin1]
+ * or NULL, res (added before the activation) and out [B,Ho,Wo,cout].  Channel counts must be
+ * multiples of 64.  act: 0 none, 1 SiLU, 2 ReLU. */
+typedef struct ldm_conv ldm_conv;
+int ldm_conv_create(ldm_conv** out, int kind, int dtype, int cin0, int cin1, int cout, const float* weight_host,
+                    const float* bias_host);
+int ldm_conv_forward(ldm_conv* c, const void* in0_dev, const void* in1_dev, const void* res_dev, void* out_dev,
+                     int B, int Hin, int Win, int act, void* stream);
+void ldm_conv_destroy(ldm_conv* c);
+
 /* ---- one scheduler update on flat f32 arrays, src/main.rs:712-756,765 --------------------- */
 /* coef5 = one row of ldm_ddpm_coefficients / ldm_ddim_coefficients.  DDPM: z <- (x0*c1 + z*c2) +
  * sigma*noise, or x0 when `last`; DDIM: z <- x0*c1 + eps*c2; x0 = (z - eps*s1m)/sa.  noise_dev may be
