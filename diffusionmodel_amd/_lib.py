@@ -50,7 +50,8 @@ SIGNATURES = {
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    # LDM_HIP_LIB: developer override to load another build of the same library
+    return os.environ.get("LDM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load() -> C.CDLL:

@@ -68,7 +68,7 @@ struct PackedConv {
     int cin = 0;            // padded total input channels (multiple of chunk)
     int cout = 0;           // padded output channels (multiple of 64)
     int ntaps = 0, nphase = 1;
-    void* w = nullptr;      // [phase][chunk][tap][cout][chunk elems], 16-byte pieces XOR-swizzled by (cout & 7)
+    void* w = nullptr;      // [phase][chunk][tap][pair plane 0..3][cout][2 pieces of 16 bytes]
     float* bias = nullptr;  // [cout]
     size_t w_bytes = 0;
 };

@@ -164,13 +164,14 @@ static int pack_conv(const PackSpec& sp, DevPool& pool, PackedConv* pc, int* src
             const int s = (sp.src.size() == 2 && c >= ch0[1]) ? 1 : 0;
             for (int t = 0; t < pc->ntaps; ++t)
                 for (int co = 0; co < pc->cout; ++co) {
-                    const size_t rowbase = ((((size_t)ph * nchunks + c) * pc->ntaps + t) * pc->cout + co) * ck;
+                    // slab = 4 pair planes; plane pp holds the 16-byte pieces 2pp and 2pp+1 of every row
+                    const size_t slab = (((size_t)ph * nchunks + c) * pc->ntaps + t) * pc->cout * ck;
                     for (int e = 0; e < ck; ++e) {
                         const int cs = (c - ch0[s]) * ck + e;
                         float v = 0.f;
                         if (co < sp.cout && cs < sp.src[s]) v = sp.w(ph, t, co, off[s] + cs);
                         const int piece = e / epp;
-                        const size_t pos = rowbase + (size_t)((piece ^ (co & 7)) * epp + e % epp);
+                        const size_t pos = slab + (((size_t)(piece >> 1) * pc->cout + co) * 2 + (piece & 1)) * epp + e % epp;
                         if (sp.dtype == LDM_BF16) wh[pos] = host_f2bf(v);
                         else wf[pos] = v;
                     }

@@ -6,14 +6,29 @@
 //   conv1x1 over two channel-concatenated sources (up_conv1/2 on cat[up, skip]; src/main.rs:468-483,516-522)
 //   and the token Linears of Attention (question/key/val/out; src/main.rs:249-252) as conv1x1.
 //
-// Work decomposition.  A workgroup (4 waves) owns TH x 16 output pixels of one image and BN output
-// channels.  The input window of the tile ("halo", (TH-1)*S+KEXT rows x (15*S+KEXT) pixels) is staged
-// into LDS once per 128-byte channel chunk (64 bf16 / 32 f32 channels) by LDS-DMA (global_load_lds,
-// 16 B per lane, zero page for out-of-image pixels) and then re-used by all taps; the weight slab of
-// one (chunk, tap) -- BN rows of 128 bytes -- is streamed through a two-deep LDS ring.  Every LDS row
-// is 128 bytes; the 16-byte piece p of row r lives at piece p ^ (r & 7) so that ds_read_b128 of
-// 16 consecutive rows is bank-conflict free (weights are stored pre-swizzled, halo loads swizzle the
-// source address, because the DMA writes LDS linearly).
+// Work decomposition.  A workgroup (4 or 8 waves) owns TH x 16 output pixels of one image and BN
+// output channels.  The input window of the tile ("halo", (TH-1)*S+KEXT rows x (15*S+KEXT) pixels) is
+// staged into LDS once per 128-byte channel chunk (64 bf16 / 32 f32 channels) by LDS-DMA
+// (global_load_lds, 16 B per lane, zero page for out-of-image pixels) and then re-used by all taps;
+// the weight slab of one (chunk, tap) -- BN rows of 128 bytes -- is streamed through a three-deep
+// LDS ring, two steps ahead of its use.
+//
+// LDS layout ("pair planes").  The 128 bytes of a row (pixel or output channel) are eight 16-byte
+// pieces; piece p lives in plane p >> 1 at row * 32 + (p & 1) * 16.  An MFMA fragment read
+// (ds_read_b128: 16 rows x the four pieces kk*4 + lane/16) then touches 16 distinct 16-byte slots of
+// every 256-byte bank row, i.e. it is conflict free with NO address swizzle, and every address is
+// one per-lane base plus compile-time immediates: row offsets of taps and fragments are multiples of
+// 32 bytes, the second half step is two planes further.  A DMA piece (1 KiB) fills 32 rows of one
+// plane; its 64 lanes read 32 bytes from each of 32 consecutive pixels (or channels; the packed
+// weights are stored plane-major so that this is a linear copy).
+//
+// Synchronisation.  One raw s_barrier per (chunk, tap) step.  Before it every wave waits with a
+// COUNTED s_waitcnt vmcnt(N) only for the DMA pieces the next step reads (its weight slab, and the
+// next chunk's halo when that chunk starts), so the slab two steps ahead and a freshly issued halo
+// stay in flight across the barrier.  Every wave issues the same number of pieces per slab (NW) and per
+// halo (NHW, padded with zero-page pieces into a dump area), which makes the counts constants.
+// Inside a step the LDS reads of the next half step are interleaved with the MFMAs of this one
+// (fragments double-buffered in registers).
 //
 // MFMA orientation: D^T = W * X^T, i.e. the A operand is the weight slab (row = output channel) and
 // the B operand the pixels (column = pixel).  A lane then owns 4 consecutive output channels of one
@@ -21,6 +36,18 @@
 // bf16 uses v_mfma_f32_16x16x32_bf16; f32 uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) four times
 // per 16-byte fragment, with the K permutation applied identically to both operands.
 #include "common.h"
+
+// Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
+// the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA.
+#ifndef TAPCONV_ABLATE
+#define TAPCONV_ABLATE 0
+#endif
+// wave layout of the 8-row x 128-channel tile (tuning knob while measuring)
+#ifndef TAPCONV_L3_WM
+#define TAPCONV_L3_WM 4
+#define TAPCONV_L3_WN 2
+#define TAPCONV_L3_MINW 2
+#endif
 
 namespace ldm {
 
@@ -42,26 +69,16 @@ struct TapConvArgs {
     int Hout, Wout, cout;
     int osc;                     // output scale: 2 for convT phases, else 1
     int ntaps;
-    unsigned long long tapcode[4];  // per phase: 4 bits per tap = dy | dx << 2 (window coordinates)
     int tiles_x, tiles_y, ntiles, nblk_n;
     int act, out_f32;
     int t_img_stride, t_step_stride;
     long w_phase_stride;         // bytes
 };
 
-template <typename T> struct Elem;
-template <> struct Elem<float> { static constexpr int CK = 32; };
-template <> struct Elem<bf16_t> { static constexpr int CK = 64; };
-
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    return __builtin_bit_cast(bf16_t, (__bf16)f);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) {
-    return __builtin_bit_cast(float, (unsigned int)h << 16);
-}
-
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
 // by-value helper: bit_cast applied directly to a vector-element expression reads element 0
 __device__ __forceinline__ float u2f(unsigned int u) { return __builtin_bit_cast(float, u); }
 
@@ -70,22 +87,45 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// TH: tile rows; BN: output channels per workgroup; WM x WN = 4 waves over (pixel rows, channels);
-// S: stride; KEXT: window extent (3 for 3x3 and the convT phases, 1 for 1x1); MINW: waves per SIMD.
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int MINW>
-__global__ __launch_bounds__(256, MINW) void tapconv_kernel(const TapConvArgs a) {
-    static_assert(WM * WN == 4, "four waves");
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Window coordinates of tap t (compile time): 3x3 -> (t/3, t%3); convT phase -> (t>>1, t&1) on top of
+// the phase's own (py, px) origin, which is added at run time; 1x1 -> (0, 0).
+template <int NTAPS>
+__device__ __forceinline__ constexpr int tap_dy(int t) { return NTAPS == 9 ? t / 3 : (NTAPS == 4 ? (t >> 1) : 0); }
+template <int NTAPS>
+__device__ __forceinline__ constexpr int tap_dx(int t) { return NTAPS == 9 ? t % 3 : (NTAPS == 4 ? (t & 1) : 0); }
+
+// TH: tile rows; BN: output channels per workgroup; WM x WN waves (4 or 8) over (pixel rows, channels);
+// S: stride; KEXT: window extent (3 for 3x3 and the convT phases, 1 for 1x1); NTAPS: taps per chunk
+// (9, 4 or 1; the tap loop is unrolled); MINW: waves per SIMD the register budget must allow.
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapConvArgs a) {
+    constexpr int NWV = WM * WN;
+    static_assert(NWV == 4 || NWV == 8, "four or eight waves");
     constexpr int TW = 16;
     constexpr int HH = (TH - 1) * S + KEXT;
     constexpr int HW = (TW - 1) * S + KEXT;
     constexpr int HP = HH * HW;
-    constexpr int NI = (HP + 7) / 8;            // 1-KiB DMA pieces per halo chunk
-    constexpr int HALO_BYTES = NI * 1024;
-    constexpr int WSLAB = BN * 128;
+    constexpr int NG = (HP + 31) / 32;           // groups of 32 halo pixels
+    constexpr int HPLANE = NG * 1024;            // one pair plane of the halo
+    constexpr int HALO_BYTES = 4 * HPLANE;
+    constexpr int NHP = NG * 4;                  // 1-KiB DMA pieces per halo chunk
+    constexpr int NHW = (NHP + NWV - 1) / NWV;   // pieces per wave (the excess goes to the dump area)
+    constexpr int WPLANE = BN * 32;
+    constexpr int WSLAB = 4 * WPLANE;
+    constexpr int NW = BN / 8 / NWV;             // weight pieces per wave and slab
+    constexpr int RING = 3;                      // weight slabs in LDS; slab s+2 is issued during step s
     constexpr int MF = TH / WM;                  // pixel fragments (tile rows) per wave
     constexpr int NF = BN / 16 / WN;             // channel fragments per wave
     constexpr int PAD = KEXT / 2;
-    static_assert(TH % WM == 0 && (BN / 16) % WN == 0, "wave tiling");
+    static_assert(TH % WM == 0 && (BN / 16) % WN == 0 && (BN / 8) % NWV == 0, "wave tiling");
+    static_assert(NW + NHW < 64, "vmcnt range");
+    static_assert(2 * HALO_BYTES + RING * WSLAB + 1024 <= 160 * 1024, "LDS budget");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,46 +149,77 @@ __global__ __launch_bounds__(256, MINW) void tapconv_kernel(const TapConvArgs a)
     const int n0 = nb * BN;
     const int iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
     const int nchunks = a.nch0 + a.nch1;
-    const int ntaps = a.ntaps;
-    const int nsteps = nchunks * ntaps;
+    const int nsteps = nchunks * NTAPS;
+    const int nhalo = nchunks > 1 ? 2 : 1;
 
-    char* hbuf0 = smem;
-    char* wbuf0 = smem + (nchunks > 1 ? 2 : 1) * HALO_BYTES;
+    // LDS: [halo 0][halo 1 if more than one chunk][weight ring][1 KiB dump]
+    const unsigned hbuf0 = 0;
+    const unsigned wbuf0 = nhalo * HALO_BYTES;
+    const unsigned dump = wbuf0 + RING * WSLAB;
 
     const char* in0_img = a.in0 + (size_t)img * a.Hin * a.Win * a.cin0_bytes;
     const char* in1_img = a.in1 ? a.in1 + (size_t)img * a.Hin * a.Win * a.cin1_bytes : nullptr;
-    const char* wbase = a.w + (size_t)phase * a.w_phase_stride + (size_t)n0 * 128;
+    const char* wbase = a.w + (size_t)phase * a.w_phase_stride + (size_t)n0 * 32;
     const size_t wslab_stride = (size_t)a.cout * 128;   // bytes between consecutive (chunk, tap) slabs
+    const size_t wplane_stride = (size_t)a.cout * 32;   // bytes between the pair planes of one slab
     const char* zero = (const char*)g_zero16;
 
-    auto issue_halo = [&](int c, int first, int stride) {
-        const char* base = c < a.nch0 ? in0_img + c * 128 : in1_img + (c - a.nch0) * 128;
+    // ---- epilogue operands that do not depend on the accumulators: fetched first, used last -------
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride : nullptr;
+    f32x4 bias4[NF], tv4[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int co = n0 + (wn * NF + nf) * 16 + g * 4;
+        bias4[nf] = *(const f32x4*)(a.bias + co);
+        tv4[nf] = tv ? *(const f32x4*)(tv + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // Halo DMA.  Wave w issues pieces e = w + NWV*q; piece e = (pixel group e >> 2, plane e & 3).  A lane
+    // covers pixel group*32 + lane/2, bytes plane*32 + (lane&1)*16 of the chunk.  The pixel's offset
+    // inside the image is the same for every chunk: computed once (-1 = zero page).
+    int hpix[NHW];
+#pragma unroll
+    for (int q = 0; q < NHW; ++q) {
+        const int grp = (wave + NWV * q) >> 2;
+        const int hp = grp * 32 + (lane >> 1);
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = grp < NG && hp < HP && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        hpix[q] = ok ? (iy * a.Win + ix) : -1;
+    }
+    auto issue_halo = [&](int c) {
+        const char* base = (c < a.nch0 ? in0_img + c * 128 : in1_img + (c - a.nch0) * 128) + (lane & 1) * 16 +
+                           (wave & 3) * 32;
         const int pix_bytes = c < a.nch0 ? a.cin0_bytes : a.cin1_bytes;
-        char* dst = hbuf0 + (c & 1) * HALO_BYTES;
-        for (int i = first; i < NI; i += stride) {
-            const int hp = i * 8 + (lane >> 3);
-            const int slot = lane & 7;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = hp < HP && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            const char* src = ok ? base + ((size_t)(iy * a.Win + ix) * pix_bytes + ((slot ^ (hp & 7)) << 4)) : zero;
-            glds16(src, dst + i * 1024);
+        const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES + (wave & 3) * HPLANE;
+#pragma unroll
+        for (int q = 0; q < NHW; ++q) {
+            const int grp = (wave + NWV * q) >> 2;       // wave-uniform
+            const char* src = hpix[q] >= 0 ? base + (size_t)hpix[q] * pix_bytes : zero;
+            const unsigned dst = grp < NG ? hb + grp * 1024 : dump;
+            if constexpr (!(TAPCONV_ABLATE & 16)) glds16(src, smem + dst);
         }
     };
-    auto issue_w = [&](int s) {
-        const char* src = wbase + (size_t)s * wslab_stride + lane * 16;
-        char* dst = wbuf0 + (s & 1) * WSLAB;
+    // Weight DMA: slab piece e = (plane e / (BN/32), 32 rows); wave w issues e = w + NWV*i.
+    auto issue_w = [&](int s, int slot) {
+        const char* sl = wbase + (size_t)s * wslab_stride + lane * 16;
+        const unsigned dst = wbuf0 + slot * WSLAB;
 #pragma unroll
-        for (int i = 0; i < BN / 8 / 4; ++i) glds16(src + (wave + i * 4) * 1024, dst + (wave + i * 4) * 1024);
+        for (int i = 0; i < NW; ++i) {
+            const int e = wave + NWV * i;
+            const int pp = e / (BN / 32), r0 = (e % (BN / 32)) * 32;
+            glds16(sl + pp * wplane_stride + r0 * 32, smem + dst + e * 1024);
+        }
     };
 
-    // per-lane LDS read offsets that do not change over the K loop
-    int wrow_off[NF];   // weight rows
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) wrow_off[nf] = ((wn * NF + nf) * 16 + l15) * 128;
-    int hp_base[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) hp_base[mf] = ((wm * MF + mf) * S) * HW + l15 * S;
+    // Per-lane LDS read bases; everything else is an immediate.
+    //   weights: plane (kk*2 + g/2), row (wn*NF + nf)*16 + l15, half g&1
+    //   halo:    plane (kk*2 + g/2), pixel ((wm*MF + mf)*S + dy)*HW + l15*S + dx, half g&1
+    const unsigned wlane = (g >> 1) * WPLANE + ((wn * NF) * 16 + l15) * 32 + (g & 1) * 16;
+    const int py = phase >> 1, px = phase & 1;
+    const int origin = NTAPS == 4 ? py * HW + px : 0;   // convT: the phase's window origin
+    const unsigned hlane = (g >> 1) * HPLANE + ((wm * MF * S) * HW + l15 * S + origin) * 32 + (g & 1) * 16;
 
     f32x4 acc[NF][MF];
 #pragma unroll
@@ -156,98 +227,192 @@ __global__ __launch_bounds__(256, MINW) void tapconv_kernel(const TapConvArgs a)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_halo(0, wave, 4);
-    issue_w(0);
-    __syncthreads();
-
-    const unsigned long long tapcode = a.tapcode[phase];
-    int c = 0, t = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) issue_w(s + 1);
-        if (c + 1 < nchunks) issue_halo(c + 1, t + ntaps * wave, ntaps * 4);
-
-        const char* hb = hbuf0 + (c & 1) * HALO_BYTES;
-        const char* wb = wbuf0 + (s & 1) * WSLAB;
-        const unsigned int code = (unsigned int)(tapcode >> (4 * t)) & 15u;
-        const int tap_off = (code & 3) * HW + (code >> 2);
-
+    // Fragment loads and the MFMA batch of one half step (32 bf16 / 16 f32 channels of one tap).
+    auto load_frags = [&](int kk, unsigned hb, unsigned wb, int t, u32x4 (&wf)[NF], u32x4 (&xf)[MF]) {
+        const char* wp = smem + wb + wlane;
+        const char* hp = smem + hb + hlane;
+        const int toff = (tap_dy<NTAPS>(t) * HW + tap_dx<NTAPS>(t)) * 32;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int piece = kk * 4 + g;
-            u32x4 wf[NF], xf[MF];
+        for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const u32x4*)(wp + kk * 2 * WPLANE + nf * 512);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-                wf[nf] = *(const u32x4*)(wb + wrow_off[nf] + ((piece ^ (l15 & 7)) << 4));
+        for (int mf = 0; mf < MF; ++mf) xf[mf] = *(const u32x4*)(hp + kk * 2 * HPLANE + mf * (S * HW * 32) + toff);
+    };
+    auto mfma_batch = [&](const u32x4 (&wf)[NF], const u32x4 (&xf)[MF]) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                const int hp = hp_base[mf] + tap_off;
-                xf[mf] = *(const u32x4*)(hb + hp * 128 + ((piece ^ (hp & 7)) << 4));
-            }
+                if constexpr (TAPCONV_ABLATE & 1) {
+                    asm volatile("" ::"v"(wf[nf]), "v"(xf[mf]));
+                } else if constexpr (sizeof(T) == 2) {
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[nf]), __builtin_bit_cast(bf16x8, xf[mf]), acc[nf][mf], 0, 0, 0);
+                } else {
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wf[nf]), __builtin_bit_cast(bf16x8, xf[mf]), acc[nf][mf], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                u2f(wf[nf][q]), u2f(xf[mf][q]), acc[nf][mf], 0, 0, 0);
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2f(wf[nf][q]), u2f(xf[mf][q]), acc[nf][mf],
+                                                                            0, 0, 0);
                 }
+            }
+    };
+    // Scheduling directive for one half step: spread the next half's LDS reads between this half's
+    // MFMAs (a burst of reads in front of the MFMAs stalls the wave at LDS issue while the matrix
+    // pipe idles).
+    auto interleave_reads_with_mfma = [&]() {
+        constexpr int NR = MF + NF;
+        constexpr int NM = MF * NF * (sizeof(T) == 2 ? 1 : 4);
+        constexpr int PER = NM / NR;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
         }
-        __syncthreads();
-        if (++t == ntaps) { t = 0; ++c; }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
+    };
+
+    // prologue: halo 0, slabs 0 and 1; wait for halo 0 and slab 0 only
+    issue_halo(0);
+    issue_w(0, 0);
+    if (nsteps > 1) {
+        issue_w(1, 1);
+        wait_vmcnt<NW>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+
+    // Software pipeline over half steps: while the MFMAs of one half run, the LDS reads of the next
+    // half are in flight (fragments double-buffered in registers: A = first half, B = second half).
+    u32x4 wfA[NF], xfA[MF], wfB[NF], xfB[MF];
+    if constexpr (!(TAPCONV_ABLATE & 4)) load_frags(0, hbuf0, wbuf0, 0, wfA, xfA);
+
+    int slot = 0, s = 0;   // slot = s % RING
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES;
+        const bool more_chunks = c + 1 < nchunks;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t, ++s) {
+            // slab s+2 goes to the ring slot that step s-1 read; every wave finished those reads
+            // before it passed that step's barrier
+            const bool halo_now = t == 0 && more_chunks;
+            if (halo_now) issue_halo(c + 1);      // older than slab s+2: a later counted wait covers it
+            const bool w_young = s + 2 < nsteps && !(TAPCONV_ABLATE & 2);
+            if (w_young) issue_w(s + 2, slot == 0 ? 2 : slot - 1);
+            const unsigned wb = wbuf0 + slot * WSLAB;
+            if constexpr (!(TAPCONV_ABLATE & 4)) {
+                load_frags(1, hb, wb, t, wfB, xfB);
+                mfma_batch(wfA, xfA);
+                interleave_reads_with_mfma();
+            }
+            // what must have landed before the next step: slab s+1 and, if it opens a chunk, that
+            // chunk's halo.  Younger pieces may stay in flight: slab s+2 (NW) and a halo issued in
+            // this very step when the next step still belongs to this chunk (NHW).  lgkmcnt(0):
+            // this step's LDS reads are complete before any wave may overwrite what they read.
+            const bool h_young = halo_now && NTAPS > 1 && !(TAPCONV_ABLATE & 16);
+            if (w_young) {
+                if (h_young) wait_vmcnt<NW + NHW>(); else wait_vmcnt<NW>();
+            } else {
+                if (h_young) wait_vmcnt<NHW>(); else wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (++slot == RING) slot = 0;
+            if constexpr (!(TAPCONV_ABLATE & 4)) {
+                // first half of the next step (after the very last step this reads LDS that nobody
+                // uses: harmless, and reads and MFMAs stay in one basic block for the interleave)
+                const bool wrap = t == NTAPS - 1;
+                const unsigned hbn = wrap ? hbuf0 + (more_chunks ? ((c + 1) & 1) : 0) * HALO_BYTES : hb;
+                load_frags(0, hbn, wbuf0 + slot * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
+                mfma_batch(wfB, xfB);
+                interleave_reads_with_mfma();
+            }
+        }
     }
 
     // ---- epilogue: + bias, (+ residual), activation, (+ time vector), store -------------------
-    const int step = a.step_ptr ? *a.step_ptr : 0;
-    const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride : nullptr;
-    const int py = phase >> 1, px = phase & 1;
+    // (py, px: the convT phase, defined above)
     const int gx = x0 + l15;
-    const int ox = gx * a.osc + px;
+    const bool xok = gx < a.Wg;
+    const int ox = (xok ? gx : a.Wg - 1) * a.osc + px;
+    size_t eo[MF];       // element offset of this lane's first channel in each pixel fragment (clamped)
+    bool ok[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int gy = y0 + wm * MF + mf;
-        if (gy >= a.Hg || gx >= a.Wg) continue;
-        const int oy = gy * a.osc + py;
-        const size_t pix = ((size_t)img * a.Hout + oy) * a.Wout + ox;
+        ok[mf] = xok && gy < a.Hg;
+        const int oy = (gy < a.Hg ? gy : a.Hg - 1) * a.osc + py;
+        eo[mf] = (((size_t)img * a.Hout + oy) * a.Wout + ox) * a.cout + n0 + wn * NF * 16 + g * 4;
+    }
+    if (a.res) {
+        // all residual loads first, one wait, then the arithmetic
+        if constexpr (sizeof(T) == 2) {
+            uint2 r[MF][NF];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            const int co = n0 + (wn * NF + nf) * 16 + g * 4;
-            const f32x4 b4 = *(const f32x4*)(a.bias + co);
-            f32x4 v = acc[nf][mf] + b4;
-            const size_t eo = pix * a.cout + co;
-            if (a.res) {
-                if constexpr (sizeof(T) == 2) {
-                    const uint2 r = *(const uint2*)(a.res + eo * 2);
-                    v[0] += bf2f((bf16_t)(r.x & 0xffffu));
-                    v[1] += bf2f((bf16_t)(r.x >> 16));
-                    v[2] += bf2f((bf16_t)(r.y & 0xffffu));
-                    v[3] += bf2f((bf16_t)(r.y >> 16));
-                } else {
-                    v += *(const f32x4*)(a.res + eo * 4);
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) r[mf][nf] = *(const uint2*)(a.res + (eo[mf] + nf * 16) * 2);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    acc[nf][mf][0] += bf2f((bf16_t)(r[mf][nf].x & 0xffffu));
+                    acc[nf][mf][1] += bf2f((bf16_t)(r[mf][nf].x >> 16));
+                    acc[nf][mf][2] += bf2f((bf16_t)(r[mf][nf].y & 0xffffu));
+                    acc[nf][mf][3] += bf2f((bf16_t)(r[mf][nf].y >> 16));
                 }
-            }
-            if (a.act == ACT_SILU) {
+        } else {
+            f32x4 r[MF][NF];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
-            } else if (a.act == ACT_RELU) {
+            for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-            }
-            if (tv) v += *(const f32x4*)(tv + co);
-            if (sizeof(T) == 4 || a.out_f32) {
-                *(f32x4*)(a.out + eo * 4) = v;
-            } else {
-                uint2 o;
-                o.x = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-                o.y = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-                *(uint2*)(a.out + eo * 2) = o;
-            }
+                for (int nf = 0; nf < NF; ++nf) r[mf][nf] = *(const f32x4*)(a.res + (eo[mf] + nf * 16) * 4);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) acc[nf][mf] += r[mf][nf];
         }
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] += bias4[nf];
+    if (a.act == ACT_SILU) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[nf][mf][q] = silu_f(acc[nf][mf][q]);
+    } else if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[nf][mf][q] = fmaxf(acc[nf][mf][q], 0.f);
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] += tv4[nf];
+    if (sizeof(T) == 4 || a.out_f32) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                if (ok[mf] && (!(TAPCONV_ABLATE & 8) || acc[nf][mf][0] == 12345.678f))
+                    *(f32x4*)(a.out + (eo[mf] + nf * 16) * 4) = acc[nf][mf];
+    } else {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                uint2 o;
+                o.x = (unsigned int)f2bf(acc[nf][mf][0]) | ((unsigned int)f2bf(acc[nf][mf][1]) << 16);
+                o.y = (unsigned int)f2bf(acc[nf][mf][2]) | ((unsigned int)f2bf(acc[nf][mf][3]) << 16);
+                if (ok[mf] && (!(TAPCONV_ABLATE & 8) || acc[nf][mf][0] == 12345.678f))
+                    *(uint2*)(a.out + (eo[mf] + nf * 16) * 2) = o;
+            }
     }
 }
 
@@ -264,24 +429,26 @@ int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
     LDM_FAIL(LDM_ERR_INVALID, "unknown conv kind");
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int MINW>
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW>
 static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
+    constexpr int NWV = WM * WN;
     constexpr int HH = (TH - 1) * S + KEXT, HW = 15 * S + KEXT;
-    constexpr int NI = (HH * HW + 7) / 8;
+    constexpr int HALO_BYTES = (HH * HW + 31) / 32 * 4096;
     const int nchunks = a.nch0 + a.nch1;
-    const size_t lds = (size_t)(nchunks > 1 ? 2 : 1) * NI * 1024 + 2 * (size_t)BN * 128;
+    const size_t lds = (size_t)(nchunks > 1 ? 2 : 1) * HALO_BYTES + 3 * (size_t)BN * 128 + 1024;
     a.tiles_x = (a.Wg + 15) / 16;
     a.tiles_y = (a.Hg + TH - 1) / TH;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     a.nblk_n = a.cout / BN;
-    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, MINW>;
+    if (a.ntaps != NTAPS) LDM_FAIL(LDM_ERR_INVALID, "tap count does not match the kernel");
+    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8 * a.nblk_n), 1, (unsigned)nphase);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }
@@ -301,30 +468,40 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;
     const int nph = pc.nphase;
     if (pc.kind == CONV3x3_S2) {
-        if (bn == 128) return launch_cfg<T, 4, 128, 2, 2, 2, 3, 1>(a, nph, stream);
-        return launch_cfg<T, 4, 64, 2, 2, 2, 3, 1>(a, nph, stream);
+        if (bn == 128) return launch_cfg<T, 4, 128, 2, 2, 2, 3, 9, 1>(a, nph, stream);
+        return launch_cfg<T, 4, 64, 2, 2, 2, 3, 9, 1>(a, nph, stream);
     }
     if (pc.kind == CONV1x1) {
         const int th = pick_th(t16, t8, nblk_n, nph, 256, true);
         if (bn == 128) {
-            if (th == 16) return launch_cfg<T, 16, 128, 2, 2, 1, 1, 1>(a, nph, stream);
-            if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 1, 1>(a, nph, stream);
-            return launch_cfg<T, 4, 128, 2, 2, 1, 1, 1>(a, nph, stream);
+            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 1, 1, 2>(a, nph, stream);
+            if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 1, 1, 1>(a, nph, stream);
+            return launch_cfg<T, 4, 128, 2, 2, 1, 1, 1, 1>(a, nph, stream);
         }
-        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 1, 2>(a, nph, stream);
-        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 2>(a, nph, stream);
-        return launch_cfg<T, 4, 64, 2, 2, 1, 1, 2>(a, nph, stream);
+        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 1, 1, 2>(a, nph, stream);
+        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
+        return launch_cfg<T, 4, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
     }
-    // 3x3-window kinds: conv3x3 stride 1 and the convT phases
+    // 3x3-window kinds: conv3x3 stride 1 (9 taps) and the convT phases (4 taps)
     const int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true);
-    if (bn == 128) {
-        if (th == 16) return launch_cfg<T, 16, 128, 2, 2, 1, 3, 1>(a, nph, stream);
-        if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 1>(a, nph, stream);
-        return launch_cfg<T, 4, 128, 2, 2, 1, 3, 1>(a, nph, stream);
+    if (pc.kind == CONV3x3_S1) {
+        if (bn == 128) {
+            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2>(a, nph, stream);
+            if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW>(a, nph, stream);
+            return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
+        }
+        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 9, 2>(a, nph, stream);
+        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
+        return launch_cfg<T, 4, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
     }
-    if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 2>(a, nph, stream);
-    if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 2>(a, nph, stream);
-    return launch_cfg<T, 4, 64, 2, 2, 1, 3, 2>(a, nph, stream);
+    if (bn == 128) {
+        if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2>(a, nph, stream);
+        if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1>(a, nph, stream);
+        return launch_cfg<T, 4, 128, 2, 2, 1, 3, 4, 1>(a, nph, stream);
+    }
+    if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 4, 2>(a, nph, stream);
+    if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 4, 2>(a, nph, stream);
+    return launch_cfg<T, 4, 64, 2, 2, 1, 3, 4, 2>(a, nph, stream);
 }
 
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream) {
@@ -352,21 +529,6 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     a.act = cc.act; a.out_f32 = (pc.dtype == LDM_F32) ? 1 : cc.out_f32;
     a.t_img_stride = cc.t_img_stride; a.t_step_stride = cc.t_step_stride;
     a.w_phase_stride = (long)(pc.cin / ck) * pc.ntaps * pc.cout * 128;
-    for (int p = 0; p < 4; ++p) a.tapcode[p] = 0;
-    if (pc.kind == CONV3x3_S1 || pc.kind == CONV3x3_S2) {
-        unsigned long long code = 0;
-        for (int t = 0; t < 9; ++t) code |= (unsigned long long)((t / 3) | ((t % 3) << 2)) << (4 * t);
-        a.tapcode[0] = code;
-    } else if (pc.kind == CONVT4x4_S2) {
-        // phase (py,px), tap (ta,tb): window row = py + ta, window col = px + tb
-        // (input row iy = i - 1 + py + ta pairs with kernel row ky = 3 - py - 2*ta; see pack_convT)
-        for (int p = 0; p < 4; ++p) {
-            const int py = p >> 1, px = p & 1;
-            unsigned long long code = 0;
-            for (int t = 0; t < 4; ++t) code |= (unsigned long long)((py + (t >> 1)) | ((px + (t & 1)) << 2)) << (4 * t);
-            a.tapcode[p] = code;
-        }
-    }
     if (pc.dtype == LDM_BF16) return launch_typed<bf16_t>(pc, cc, a, stream);
     return launch_typed<float>(pc, cc, a, stream);
 }
