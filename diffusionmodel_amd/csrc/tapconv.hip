@@ -43,6 +43,15 @@
 #define TAPCONV_ABLATE 0
 #endif
 // wave layout of the 8-row x 128-channel tile (tuning knob while measuring)
+#ifndef TAPCONV_RING_L1
+#define TAPCONV_RING_L1 3
+#endif
+#ifndef TAPCONV_RING_L2
+#define TAPCONV_RING_L2 3
+#endif
+#ifndef TAPCONV_RING_L3
+#define TAPCONV_RING_L3 3
+#endif
 #ifndef TAPCONV_L3_WM
 #define TAPCONV_L3_WM 4
 #define TAPCONV_L3_WN 2
@@ -103,7 +112,7 @@ __device__ __forceinline__ constexpr int tap_dx(int t) { return NTAPS == 9 ? t %
 // TH: tile rows; BN: output channels per workgroup; WM x WN waves (4 or 8) over (pixel rows, channels);
 // S: stride; KEXT: window extent (3 for 3x3 and the convT phases, 1 for 1x1); NTAPS: taps per chunk
 // (9, 4 or 1; the tap loop is unrolled); MINW: waves per SIMD the register budget must allow.
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW>
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapConvArgs a) {
     constexpr int NWV = WM * WN;
     static_assert(NWV == 4 || NWV == 8, "four or eight waves");
@@ -119,13 +128,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     constexpr int WPLANE = BN * 32;
     constexpr int WSLAB = 4 * WPLANE;
     constexpr int NW = BN / 8 / NWV;             // weight pieces per wave and slab
-    constexpr int RING = 3;                      // weight slabs in LDS; slab s+2 is issued during step s
+    constexpr int D = RING - 1;                  // RING weight slabs in LDS; slab s+D is issued during step s
     constexpr int MF = TH / WM;                  // pixel fragments (tile rows) per wave
     constexpr int NF = BN / 16 / WN;             // channel fragments per wave
     constexpr int PAD = KEXT / 2;
     static_assert(TH % WM == 0 && (BN / 16) % WN == 0 && (BN / 8) % NWV == 0, "wave tiling");
-    static_assert(NW + NHW < 64, "vmcnt range");
-    static_assert(2 * HALO_BYTES + RING * WSLAB + 1024 <= 160 * 1024, "LDS budget");
+    static_assert((D - 1) * NW + NHW < 64 && D >= 1 && D <= 5, "vmcnt range");
+    static_assert(HALO_BYTES + RING * WSLAB + 1024 <= 160 * 1024, "LDS budget");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -163,17 +172,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const size_t wslab_stride = (size_t)a.cout * 128;   // bytes between consecutive (chunk, tap) slabs
     const size_t wplane_stride = (size_t)a.cout * 32;   // bytes between the pair planes of one slab
     const char* zero = (const char*)g_zero16;
-
-    // ---- epilogue operands that do not depend on the accumulators: fetched first, used last -------
-    const int step = a.step_ptr ? *a.step_ptr : 0;
-    const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride : nullptr;
-    f32x4 bias4[NF], tv4[NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        const int co = n0 + (wn * NF + nf) * 16 + g * 4;
-        bias4[nf] = *(const f32x4*)(a.bias + co);
-        tv4[nf] = tv ? *(const f32x4*)(tv + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
 
     // Halo DMA.  Wave w issues pieces e = w + NWV*q; piece e = (pixel group e >> 2, plane e & 3).  A lane
     // covers pixel group*32 + lane/2, bytes plane*32 + (lane&1)*16 of the chunk.  The pixel's offset
@@ -270,15 +268,32 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
     };
 
-    // prologue: halo 0, slabs 0 and 1; wait for halo 0 and slab 0 only
+    // Counted wait: leave the `young` youngest weight slabs (and a halo, if `halo`) in flight.
+    auto wait_leaving = [&](int young, bool halo) {
+        if (halo) {
+            switch (young) {
+                case 0: wait_vmcnt<NHW>(); break;
+                case 1: wait_vmcnt<(D >= 2 ? 1 : 0) * NW + NHW>(); break;
+                case 2: wait_vmcnt<(D >= 3 ? 2 : 0) * NW + NHW>(); break;
+                case 3: wait_vmcnt<(D >= 4 ? 3 : 0) * NW + NHW>(); break;
+                default: wait_vmcnt<(D >= 5 ? 4 : 0) * NW + NHW>(); break;
+            }
+        } else {
+            switch (young) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<(D >= 2 ? 1 : 0) * NW>(); break;
+                case 2: wait_vmcnt<(D >= 3 ? 2 : 0) * NW>(); break;
+                case 3: wait_vmcnt<(D >= 4 ? 3 : 0) * NW>(); break;
+                default: wait_vmcnt<(D >= 5 ? 4 : 0) * NW>(); break;
+            }
+        }
+    };
+
+    // prologue: halo 0, then slabs 0 .. D-1; wait for halo 0 and slab 0 only
     issue_halo(0);
-    issue_w(0, 0);
-    if (nsteps > 1) {
-        issue_w(1, 1);
-        wait_vmcnt<NW>();
-    } else {
-        wait_vmcnt<0>();
-    }
+    const int npro = nsteps < D ? nsteps : D;
+    for (int d = 0; d < npro; ++d) issue_w(d, d);
+    wait_leaving(npro - 1, false);
     __builtin_amdgcn_s_barrier();
 
     // Software pipeline over half steps: while the MFMAs of one half run, the LDS reads of the next
@@ -292,28 +307,26 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         const bool more_chunks = c + 1 < nchunks;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t, ++s) {
-            // slab s+2 goes to the ring slot that step s-1 read; every wave finished those reads
+            // slab s+D goes to the ring slot that step s-1 read; every wave finished those reads
             // before it passed that step's barrier
             const bool halo_now = t == 0 && more_chunks;
-            if (halo_now) issue_halo(c + 1);      // older than slab s+2: a later counted wait covers it
-            const bool w_young = s + 2 < nsteps && !(TAPCONV_ABLATE & 2);
-            if (w_young) issue_w(s + 2, slot == 0 ? 2 : slot - 1);
+            if (halo_now) issue_halo(c + 1);      // older than slab s+D: a later counted wait covers it
+            if (s + D < nsteps && !(TAPCONV_ABLATE & 2)) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
             const unsigned wb = wbuf0 + slot * WSLAB;
             if constexpr (!(TAPCONV_ABLATE & 4)) {
                 load_frags(1, hb, wb, t, wfB, xfB);
                 mfma_batch(wfA, xfA);
                 interleave_reads_with_mfma();
             }
-            // what must have landed before the next step: slab s+1 and, if it opens a chunk, that
-            // chunk's halo.  Younger pieces may stay in flight: slab s+2 (NW) and a halo issued in
-            // this very step when the next step still belongs to this chunk (NHW).  lgkmcnt(0):
-            // this step's LDS reads are complete before any wave may overwrite what they read.
-            const bool h_young = halo_now && NTAPS > 1 && !(TAPCONV_ABLATE & 16);
-            if (w_young) {
-                if (h_young) wait_vmcnt<NW + NHW>(); else wait_vmcnt<NW>();
-            } else {
-                if (h_young) wait_vmcnt<NHW>(); else wait_vmcnt<0>();
-            }
+            // What must have landed before the next step: slab s+1 and, if it opens a chunk, that
+            // chunk's halo.  Younger pieces may stay in flight: the slabs s+2 .. s+D that exist, and
+            // the next chunk's halo while it is younger than slab s+1 (it was issued at tap 0, slab
+            // s+1 at step s+1-D) and the next step still belongs to this chunk.  lgkmcnt(0): this
+            // step's LDS reads are complete before any wave may overwrite what they read.
+            const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
+            const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - (s + 1) > 0 ? last - (s + 1) : 0);
+            const bool h_young = more_chunks && t <= D - 2 && t <= NTAPS - 2 && !(TAPCONV_ABLATE & 16);
+            wait_leaving(young, h_young);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (++slot == RING) slot = 0;
@@ -329,90 +342,92 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         }
     }
 
-    // ---- epilogue: + bias, (+ residual), activation, (+ time vector), store -------------------
-    // (py, px: the convT phase, defined above)
-    const int gx = x0 + l15;
-    const bool xok = gx < a.Wg;
-    const int ox = (xok ? gx : a.Wg - 1) * a.osc + px;
-    size_t eo[MF];       // element offset of this lane's first channel in each pixel fragment (clamped)
-    bool ok[MF];
+    // ---- epilogue ---------------------------------------------------------------------------
+    // The accumulators (4 channels of one pixel per lane) go through LDS so that global memory is
+    // touched in whole rows: every thread then owns 8 consecutive channels of a pixel, i.e. 16 bytes of
+    // bf16 (32 of f32), consecutive threads consecutive addresses; the residual is read the same way.
+    //   v = acc + bias (+ residual) -> activation -> (+ time vector) -> store
+    // All operand buffers in LDS are dead here (every wave is past the last barrier; the DMA queue
+    // was drained by the last counted wait).
+    constexpr int BM = TH * 16;
+    constexpr int RS = BN * 4 + 16;              // staging row stride (bytes): +16 keeps ds_write_b128 conflict free
+    constexpr int NTHR = 64 * NWV;
+    constexpr int CG = BN / 8;                   // 8-channel groups per pixel
+    constexpr int NIT = BM * CG / NTHR;
+    static_assert(NTHR % CG == 0 && (BM * CG) % NTHR == 0, "epilogue tiling");
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-        const int gy = y0 + wm * MF + mf;
-        ok[mf] = xok && gy < a.Hg;
-        const int oy = (gy < a.Hg ? gy : a.Hg - 1) * a.osc + py;
-        eo[mf] = (((size_t)img * a.Hout + oy) * a.Wout + ox) * a.cout + n0 + wn * NF * 16 + g * 4;
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int p = (wm * MF + mf) * 16 + l15;
+            const int ch = (wn * NF + nf) * 16 + g * 4;
+            *(f32x4*)(smem + p * RS + ch * 4) = acc[nf][mf];
+        }
+    const int cg = tid % CG;                     // the same for every iteration of this thread
+    const int co = n0 + cg * 8;
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co : nullptr;
+    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+    if (tv) { t0 = *(const f32x4*)tv; t1 = *(const f32x4*)(tv + 4); }
+    size_t eo[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int p = (tid + i * NTHR) / CG;
+        const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+        ok[i] = gy < a.Hg && gx < a.Wg;
+        const int oy = (gy < a.Hg ? gy : a.Hg - 1) * a.osc + py, ox = (gx < a.Wg ? gx : a.Wg - 1) * a.osc + px;
+        eo[i] = (((size_t)img * a.Hout + oy) * a.Wout + ox) * a.cout + co;
     }
+    f32x4 r0[NIT], r1[NIT];
     if (a.res) {
-        // all residual loads first, one wait, then the arithmetic
-        if constexpr (sizeof(T) == 2) {
-            uint2 r[MF][NF];
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
+        for (int i = 0; i < NIT; ++i) {
+            if constexpr (sizeof(T) == 2) {
+                const u32x4 r = *(const u32x4*)(a.res + eo[i] * 2);
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) r[mf][nf] = *(const uint2*)(a.res + (eo[mf] + nf * 16) * 2);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                    acc[nf][mf][0] += bf2f((bf16_t)(r[mf][nf].x & 0xffffu));
-                    acc[nf][mf][1] += bf2f((bf16_t)(r[mf][nf].x >> 16));
-                    acc[nf][mf][2] += bf2f((bf16_t)(r[mf][nf].y & 0xffffu));
-                    acc[nf][mf][3] += bf2f((bf16_t)(r[mf][nf].y >> 16));
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int u = r[q];
+                    (q < 2 ? r0[i] : r1[i])[(q & 1) * 2] = bf2f((bf16_t)(u & 0xffffu));
+                    (q < 2 ? r0[i] : r1[i])[(q & 1) * 2 + 1] = bf2f((bf16_t)(u >> 16));
                 }
-        } else {
-            f32x4 r[MF][NF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) r[mf][nf] = *(const f32x4*)(a.res + (eo[mf] + nf * 16) * 4);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) acc[nf][mf] += r[mf][nf];
+            } else {
+                r0[i] = *(const f32x4*)(a.res + eo[i] * 4);
+                r1[i] = *(const f32x4*)(a.res + eo[i] * 4 + 16);
+            }
         }
     }
+    __syncthreads();
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+    for (int i = 0; i < NIT; ++i) {
+        const int p = (tid + i * NTHR) / CG;
+        f32x4 v0 = *(const f32x4*)(smem + p * RS + cg * 32) + b0;
+        f32x4 v1 = *(const f32x4*)(smem + p * RS + cg * 32 + 16) + b1;
+        if (a.res) { v0 += r0[i]; v1 += r1[i]; }
+        if (a.act == ACT_SILU) {
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] += bias4[nf];
-    if (a.act == ACT_SILU) {
+            for (int q = 0; q < 4; ++q) { v0[q] = silu_f(v0[q]); v1[q] = silu_f(v1[q]); }
+        } else if (a.act == ACT_RELU) {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[nf][mf][q] = silu_f(acc[nf][mf][q]);
-    } else if (a.act == ACT_RELU) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[nf][mf][q] = fmaxf(acc[nf][mf][q], 0.f);
-    }
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] += tv4[nf];
-    if (sizeof(T) == 4 || a.out_f32) {
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-                if (ok[mf] && (!(TAPCONV_ABLATE & 8) || acc[nf][mf][0] == 12345.678f))
-                    *(f32x4*)(a.out + (eo[mf] + nf * 16) * 4) = acc[nf][mf];
-    } else {
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                uint2 o;
-                o.x = (unsigned int)f2bf(acc[nf][mf][0]) | ((unsigned int)f2bf(acc[nf][mf][1]) << 16);
-                o.y = (unsigned int)f2bf(acc[nf][mf][2]) | ((unsigned int)f2bf(acc[nf][mf][3]) << 16);
-                if (ok[mf] && (!(TAPCONV_ABLATE & 8) || acc[nf][mf][0] == 12345.678f))
-                    *(uint2*)(a.out + (eo[mf] + nf * 16) * 2) = o;
+            for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+        }
+        v0 += t0;
+        v1 += t1;
+        const bool st = ok[i] && (!(TAPCONV_ABLATE & 8) || v0[0] == 12345.678f);
+        if (sizeof(T) == 4 || a.out_f32) {
+            if (st) {
+                *(f32x4*)(a.out + eo[i] * 4) = v0;
+                *(f32x4*)(a.out + eo[i] * 4 + 16) = v1;
             }
+        } else {
+            u32x4 o;
+            o[0] = (unsigned int)f2bf(v0[0]) | ((unsigned int)f2bf(v0[1]) << 16);
+            o[1] = (unsigned int)f2bf(v0[2]) | ((unsigned int)f2bf(v0[3]) << 16);
+            o[2] = (unsigned int)f2bf(v1[0]) | ((unsigned int)f2bf(v1[1]) << 16);
+            o[3] = (unsigned int)f2bf(v1[2]) | ((unsigned int)f2bf(v1[3]) << 16);
+            if (st) *(u32x4*)(a.out + eo[i] * 2) = o;
+        }
     }
 }
 
@@ -429,19 +444,22 @@ int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
     LDM_FAIL(LDM_ERR_INVALID, "unknown conv kind");
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW>
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING = 3>
 static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     constexpr int NWV = WM * WN;
     constexpr int HH = (TH - 1) * S + KEXT, HW = 15 * S + KEXT;
     constexpr int HALO_BYTES = (HH * HW + 31) / 32 * 4096;
     const int nchunks = a.nch0 + a.nch1;
-    const size_t lds = (size_t)(nchunks > 1 ? 2 : 1) * HALO_BYTES + 3 * (size_t)BN * 128 + 1024;
+    size_t lds = (size_t)(nchunks > 1 ? 2 : 1) * HALO_BYTES + RING * (size_t)BN * 128 + 1024;
+    const size_t staging = (size_t)TH * 16 * (BN * 4 + 16);   // epilogue: f32 tile with padded rows
+    if (lds < staging) lds = staging;
+    static_assert((size_t)TH * 16 * (BN * 4 + 16) <= 160 * 1024, "epilogue staging exceeds LDS");
     a.tiles_x = (a.Wg + 15) / 16;
     a.tiles_y = (a.Hg + TH - 1) / TH;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     a.nblk_n = a.cout / BN;
     if (a.ntaps != NTAPS) LDM_FAIL(LDM_ERR_INVALID, "tap count does not match the kernel");
-    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW>;
+    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW, RING>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -486,11 +504,11 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     const int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true);
     if (pc.kind == CONV3x3_S1) {
         if (bn == 128) {
-            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2>(a, nph, stream);
-            if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW>(a, nph, stream);
+            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
+            if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
         }
-        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 9, 2>(a, nph, stream);
+        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 9, 2, TAPCONV_RING_L1>(a, nph, stream);
         if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
     }
