@@ -1,0 +1,120 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py).
+
+CPU: the restatement still reproduces them (pins the oracle against drift).
+GPU: the HIP path reproduces them through the C ABI, with no oracle in the loop.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import TOL, rel_err
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU: oracle vs fixtures
+# ---------------------------------------------------------------------------------------------
+def test_oracle_reproduces_schedule_and_embedding():
+    from oracle import ldm_oracle as O
+    g = load("schedule")
+    assert np.array_equal(O.get_betas(50), g["betas50"]) and np.array_equal(O.get_alphas(1000), g["abar1000"])
+    assert np.array_equal(O.ddpm_coefficients(50), g["ddpm50"])
+    assert np.array_equal(O.ddim_coefficients(1000, 50), g["ddim"])
+    assert O.ddim_timesteps(1000, 50) == list(g["ddim_ts"])
+    e = O.sin_time_addition(torch.from_numpy(g["sin_t"]).long(), 256).numpy()
+    assert np.allclose(e, g["sin_emb"], atol=1e-6)
+
+
+def test_host_schedule_matches_golden():
+    from diffusionmodel_amd import schedule
+    g = load("schedule")
+    assert np.array_equal(schedule.get_betas(1000), g["betas1000"])
+    assert np.array_equal(schedule.get_alphas(50), g["abar50"])
+    assert np.array_equal(schedule.ddpm_coefficients(1000), g["ddpm1000"])
+    assert np.array_equal(schedule.ddim_coefficients(1000, 50), g["ddim"])
+
+
+def test_oracle_reproduces_unet_and_chain():
+    from diffusionmodel_amd import LDMConfig, make_synthetic_weights
+    from oracle import ldm_oracle as O
+    w = make_synthetic_weights(LDMConfig(), 0)
+    g = load("unet")
+    x = torch.from_numpy(g["lat4_x"])
+    te = O.sin_time_addition(torch.from_numpy(g["lat4_t"]).long(), 256)
+    assert rel_err(O.unet_forward(w, x, te), torch.from_numpy(g["lat4_eps"])) < 1e-5
+    c = load("chains")
+    z0, noise = randn((4, 64, 4, 4), 1234), randn((50, 4, 64, 4, 4), 4321)
+    z = O.denoising_process(w, z0, 50, noise=noise)
+    assert rel_err(z, torch.from_numpy(c["ddpm_final"])) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: HIP path vs fixtures
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_embedding_matches_golden():
+    import diffusionmodel_amd as A
+    g = load("schedule")
+    got = A.sin_time_addition(torch.from_numpy(g["sin_t"]).cuda(), 256)
+    assert np.abs(got.cpu().numpy() - g["sin_emb"]).max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gpu_ops_match_golden(dtype):
+    import diffusionmodel_amd as A
+    from diffusionmodel_amd.weights import attention_param_shapes, resblock_param_shapes, synthetic_from_shapes
+    g = load("ops")
+    rb = A.ResiduelBlock(64, 256, dtype=dtype, weights=synthetic_from_shapes(resblock_param_shapes(64, 256), 11))
+    y = rb(torch.from_numpy(g["res_x"]).cuda(), torch.from_numpy(g["res_t"]).cuda())
+    assert rel_err(y, torch.from_numpy(g["res_y"])) < TOL[dtype]
+    at = A.Attention(128, dtype=dtype, weights=synthetic_from_shapes(attention_param_shapes(128), 5))
+    y = at(torch.from_numpy(g["att_x"]).cuda())
+    assert rel_err(y, torch.from_numpy(g["att_y"])) < TOL[dtype]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gpu_unet_matches_golden(dtype):
+    import diffusionmodel_amd as A
+    g = load("unet")
+    net = A.UNet(64, 256, dtype=dtype, weights=A.make_synthetic_weights(A.LDMConfig(), 0))
+    for name in ("lat4", "s16"):
+        te = A.sin_time_addition(torch.from_numpy(g[name + "_t"]).cuda(), 256)
+        eps = net(torch.from_numpy(g[name + "_x"]).cuda(), te)
+        e = rel_err(eps, torch.from_numpy(g[name + "_eps"]))
+        print(f"golden unet {name} {dtype}: rel_err={e:.3e}", flush=True)
+        assert e < TOL[dtype]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gpu_chains_match_golden(dtype):
+    import diffusionmodel_amd as A
+    c = load("chains")
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    m = A.DiffusionModel(64, 3, 50, 256, dtype=dtype, weights=w)
+    z0, noise = randn((4, 64, 4, 4), 1234), randn((50, 4, 64, 4, 4), 4321)
+    z, zs, eps = m.denoising_process(4, spatial=4, z0=z0.cuda(), noise=noise.cuda(), use_graph=False, return_trace=True)
+    e_final = rel_err(z, torch.from_numpy(c["ddpm_final"]))
+    e_eps = max(rel_err(eps[k], torch.from_numpy(c[f"ddpm_eps{k}"])) for k in (0, 25, 49))
+    print(f"golden ddpm {dtype}: final={e_final:.3e} eps(free-running)={e_eps:.3e}", flush=True)
+    assert rel_err(eps[0], torch.from_numpy(c["ddpm_eps0"])) < TOL[dtype]
+    assert e_final < (1e-4 if dtype == "fp32" else 5e-2)
+    m2 = A.DiffusionModel(64, 3, 1000, 256, dtype=dtype, weights=w)
+    z0 = randn((2, 64, 8, 8), 7)
+    z = m2.ddim_sample(2, 50, spatial=8, z0=z0.cuda())
+    e = rel_err(z, torch.from_numpy(c["ddim_final"]))
+    print(f"golden ddim {dtype}: final={e:.3e}", flush=True)
+    assert e < (1e-3 if dtype == "fp32" else 0.2)
