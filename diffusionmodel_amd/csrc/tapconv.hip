@@ -36,6 +36,7 @@
 // bf16 uses v_mfma_f32_16x16x32_bf16; f32 uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) four times
 // per 16-byte fragment, with the K permutation applied identically to both operands.
 #include "common.h"
+#include <cstdlib>
 
 // Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
 // the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA.
@@ -43,6 +44,9 @@
 #define TAPCONV_ABLATE 0
 #endif
 // wave layout of the 8-row x 128-channel tile (tuning knob while measuring)
+#ifndef TAPCONV_NO_WS64
+#define TAPCONV_NO_WS64 0
+#endif
 #ifndef TAPCONV_RING_L1
 #define TAPCONV_RING_L1 3
 #endif
@@ -82,7 +86,21 @@ struct TapConvArgs {
     int act, out_f32;
     int t_img_stride, t_step_stride;
     long w_phase_stride;         // bytes
+    unsigned long long* dbg;     // cycle stamps (diagnostic builds with TAPCONV_STAMP only), else null
 };
+
+#ifdef TAPCONV_STAMP
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (a.dbg && blockIdx.x == 0 && wave == 0) {                                               \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            if (lane == 0 && (i) < 64) a.dbg[(i)] = t_;                                             \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
@@ -432,6 +450,197 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight-stationary persistent variant: conv3x3 stride 1, 64 -> 64 channels, bf16 (the 64-channel
+// level of the UNet: down1, down_res1, up_res2, out_conv).  At that level a launch moves 67-100 MB
+// through HBM for 19 GFLOP; per tile the generic kernel spends more time on its DMA steps, barriers
+// and epilogue than on MFMAs.  Here a workgroup of 4 waves walks over 8x16-pixel tiles; every wave
+// keeps the weight fragments of its 32 output channels (18 half steps x 2 fragments = 144 registers)
+// in registers for the whole kernel, so per tile only the halo crosses LDS (double-buffered: the
+// next tile's halo is DMA'd while this tile computes), there is ONE barrier per tile, and the epilogue
+// needs no LDS: a lane swaps one accumulator with lane^16 and then owns 8 consecutive channels of a
+// pixel (16-byte stores).  Two workgroups share a CU and drift apart, so one computes while the other
+// is in its memory phases.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs a) {
+    constexpr int TH = 8, HW = 18, HP = 10 * 18, NG = (HP + 31) / 32;
+    constexpr int HPLANE = NG * 1024, HALO_BYTES = 4 * HPLANE;       // 4 waves: piece q of wave w = (group q, plane w)
+    constexpr int WN = 2, MF = 4, NF = 2, KS = 18;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 4, l15 = lane & 15;
+    const char* zero = (const char*)g_zero16;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    STAMP(0);
+#ifdef TAPCONV_WS_STAGGER
+    // Workgroups that start together stay in phase (all compute, then all store); delaying the second
+    // half of the grid by about half a tile period lets one workgroup's memory phase overlap the
+    // other's MFMA phase.  Speed only.
+    if (blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < TAPCONV_WS_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
+
+    // this wave's 32 output channels of every (tap, half), straight from the packed weights (L2)
+    u32x4 wreg[KS][NF];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            wreg[ks][nf] = *(const u32x4*)(a.w + (ks >> 1) * 8192 + ((ks & 1) * 2 + (g >> 1)) * 2048 +
+                                           ((wn * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
+
+    // halo DMA: window coordinates of this lane's pixel in each piece do not depend on the tile
+    int hyx[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const int hp = q * 32 + (lane >> 1);
+        const int hy = hp / HW, hx = hp - hy * HW;
+        hyx[q] = hp < HP ? (hy << 8 | hx) : -1;
+    }
+    auto issue_halo = [&](int t, int buf) {
+        const int img = t / tiles_per_img;
+        const int trem = t - img * tiles_per_img;
+        const int iy0 = (trem / a.tiles_x) * TH - 1, ix0 = (trem % a.tiles_x) * 16 - 1;
+        const char* base = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
+        const unsigned hb = buf * HALO_BYTES + wave * HPLANE;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const int iy = iy0 + (hyx[q] >> 8), ix = ix0 + (hyx[q] & 255);
+            const bool ok = hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const char* src = ok ? base + (size_t)(iy * a.Win + ix) * 128 : zero;
+            glds16(src, smem + hb + q * 1024);
+        }
+    };
+    issue_halo(tile, 0);
+
+    // epilogue constants: after the lane swap this lane owns channels co .. co+7 of pixel column l15
+    const unsigned hlane = (g >> 1) * HPLANE + ((wm * MF) * HW + l15) * 32 + (g & 1) * 16;
+    const int co = wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
+    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    const int nstore = a.out_f32 ? 2 * MF : MF;
+
+    int buf = 0;
+    bool first = true;
+    STAMP(1);
+    int sidx = 2;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        // this tile's halo has landed; only the previous epilogue's stores may still be in flight
+        if (first) wait_vmcnt<0>();
+        else if (nstore == MF) wait_vmcnt<MF>();
+        else wait_vmcnt<2 * MF>();
+        first = false;
+        __builtin_amdgcn_s_barrier();      // also: every wave is done reading the other halo buffer
+        STAMP(sidx); ++sidx;
+        const int next = tile + gridDim.x;
+        if (next < a.ntiles && !(TAPCONV_ABLATE & 16)) issue_halo(next, buf ^ 1);
+        STAMP(sidx); ++sidx;
+
+        f32x4 acc[NF][MF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hp0 = smem + buf * HALO_BYTES + hlane;
+        u32x4 xf[2][MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) xf[0][mf] = *(const u32x4*)(hp0 + mf * (HW * 32));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                const int t = (ks + 1) >> 1, kk = (ks + 1) & 1;
+                const int off = kk * 2 * HPLANE + ((t / 3) * HW + (t % 3)) * 32;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) xf[(ks + 1) & 1][mf] = *(const u32x4*)(hp0 + off + mf * (HW * 32));
+            }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    if constexpr (TAPCONV_ABLATE & 1)
+                        asm volatile("" ::"v"(wreg[ks][nf]), "v"(xf[ks & 1][mf]));
+                    else
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[ks & 1][mf]),
+                            acc[nf][mf], 0, 0, 0);
+                }
+            if (ks + 1 < KS && !(TAPCONV_ABLATE & 1)) {
+#pragma unroll
+                for (int r = 0; r < MF; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        STAMP(sidx); ++sidx;
+
+        // ---- epilogue: v = acc + bias (+ residual) -> activation -> (+ time vector) -> store ----
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
+        const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co : nullptr;
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+        if (tv) { t0 = *(const f32x4*)tv; t1 = *(const f32x4*)(tv + 4); }
+        const size_t e0 = (((size_t)img * a.Hout + y0 + wm * MF) * a.Wout + x0 + l15) * 64 + co;
+        const size_t erow = (size_t)a.Wout * 64;
+        u32x4 rr[MF];
+        if (a.res) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) rr[mf] = *(const u32x4*)(a.res + (e0 + mf * erow) * 2);
+        }
+        const bool odd = g & 1;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            // lanes g and g^1 swap one accumulator: g even keeps channel fragment 0 and receives the
+            // partner's fragment 0 (the next 4 channels); g odd keeps fragment 1 and receives fragment 1
+            const f32x4 send = odd ? acc[0][mf] : acc[1][mf];
+            f32x4 recv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) recv[q] = __shfl_xor(send[q], 16);
+            f32x4 v0 = (odd ? recv : acc[0][mf]) + b0;
+            f32x4 v1 = (odd ? acc[1][mf] : recv) + b1;
+            if (a.res) {
+                const unsigned int u0 = rr[mf][0], u1 = rr[mf][1], u2 = rr[mf][2], u3 = rr[mf][3];
+                v0[0] += bf2f((bf16_t)(u0 & 0xffffu)); v0[1] += bf2f((bf16_t)(u0 >> 16));
+                v0[2] += bf2f((bf16_t)(u1 & 0xffffu)); v0[3] += bf2f((bf16_t)(u1 >> 16));
+                v1[0] += bf2f((bf16_t)(u2 & 0xffffu)); v1[1] += bf2f((bf16_t)(u2 >> 16));
+                v1[2] += bf2f((bf16_t)(u3 & 0xffffu)); v1[3] += bf2f((bf16_t)(u3 >> 16));
+            }
+            if (a.act == ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v0[q] = silu_f(v0[q]); v1[q] = silu_f(v1[q]); }
+            } else if (a.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+            v0 += t0;
+            v1 += t1;
+            // every store is issued (the launcher only picks this kernel when tiles cover the image
+            // exactly), so each wave has the same number of stores in flight for the counted wait above
+            const size_t eo = e0 + mf * erow;
+            if (a.out_f32) {
+                *(f32x4*)(a.out + eo * 4) = v0;
+                *(f32x4*)(a.out + eo * 4 + 16) = v1;
+            } else {
+                u32x4 o;
+                o[0] = (unsigned int)f2bf(v0[0]) | ((unsigned int)f2bf(v0[1]) << 16);
+                o[1] = (unsigned int)f2bf(v0[2]) | ((unsigned int)f2bf(v0[3]) << 16);
+                o[2] = (unsigned int)f2bf(v1[0]) | ((unsigned int)f2bf(v1[1]) << 16);
+                o[3] = (unsigned int)f2bf(v1[2]) | ((unsigned int)f2bf(v1[3]) << 16);
+                if (!(TAPCONV_ABLATE & 8) || v0[0] == 12345.678f) *(u32x4*)(a.out + eo * 2) = o;
+            }
+        }
+        STAMP(sidx); ++sidx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -478,9 +687,36 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
     return 4;
 }
 
+static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        LDM_HIP(hipGetDevice(&dev));
+        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    a.tiles_x = a.Wg / 16;
+    a.tiles_y = a.Hg / 8;
+    a.ntiles = a.tiles_x * a.tiles_y * a.B;
+    a.nblk_n = 1;
+    const size_t lds = 2 * 6 * 4096;                 // two halo buffers of 10x18 pixels
+    const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+#ifdef TAPCONV_STAMP
+    if (const char* e = getenv("LDM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
+    hipLaunchKernelGGL(tapconv_ws64_kernel, dim3(grid), dim3(256), lds, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     const int bn = (a.cout % 128 == 0) ? 128 : 64;
+    if constexpr (sizeof(T) == 2) {
+        // 64 -> 64 channels, exact 16x16 tiling, at least one tile per CU: weight-stationary kernel
+        if (pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 && a.Hg % 8 == 0 && a.Wg % 16 == 0 &&
+            (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512 && !TAPCONV_NO_WS64)
+            return launch_ws64(a, stream);
+    }
     const int nblk_n = a.cout / bn;
     const long tx = (a.Wg + 15) / 16;
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;

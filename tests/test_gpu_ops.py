@@ -77,7 +77,8 @@ def test_philox_normal(A, O):
 
 # ---- ResidualBlock (conv3x3 + folded BN + SiLU + time add + residual) ---------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("C,B,H,W", [(64, 2, 8, 8), (128, 2, 4, 4), (64, 1, 20, 36), (256, 3, 16, 16), (64, 2, 64, 64)])
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 8, 8), (128, 2, 4, 4), (64, 1, 20, 36), (256, 3, 16, 16), (64, 2, 64, 64),
+                                      (64, 17, 64, 64), (64, 5, 48, 160)])
 def test_resblock(A, O, dtype, C, B, H, W):
     from diffusionmodel_amd.weights import resblock_param_shapes, synthetic_from_shapes
     w = synthetic_from_shapes(resblock_param_shapes(C, 256), 11)
