@@ -85,7 +85,16 @@ struct ConvCall {
     int out_f32 = 0;             // write f32 although dtype is bf16
     int act = ACT_NONE;
     int B = 0, Hin = 0, Win = 0; // Hout/Wout follow from the kind
+    // Fused deterministic DDIM update (only where tapconv_can_fuse_ddim says so): the conv result is
+    // the predicted noise; ddim_z [B,H,W,64] f32 is updated in place with row *step_ptr of ddim_coef
+    // ([steps][8], see SchedArgs) and `out` receives the bf16 copy of the new state.
+    // With ddim_ticket (a device word that is 0 between launches) the launch also advances *step_ptr
+    // by one when its last workgroup finishes.
+    float* ddim_z = nullptr;
+    const float* ddim_coef = nullptr;
+    int* ddim_ticket = nullptr;
 };
+bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W);
 
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
@@ -125,7 +134,7 @@ struct SchedArgs {
     unsigned int chain0;   // global index of the first chain held by this process
     const unsigned int* rng;   // optional device words {seed low, seed high, chain0}: override the two above
 };
-// ctl[0] = 0 (step counter), ctl[1..3] = {seed low, seed high, chain0}
+// ctl[0] = 0 (step counter), ctl[1..3] = {seed low, seed high, chain0}, ctl[4] = 0 (workgroup ticket of the fused update)
 int launch_set_ctl(int* ctl, unsigned long long seed, unsigned int chain0, hipStream_t s);
 int launch_sched_step(const SchedArgs& a, hipStream_t s);
 int launch_step_advance(int* step_ptr, hipStream_t s);

@@ -146,6 +146,7 @@ __global__ void set_ctl_kernel(int* ctl, unsigned int s0, unsigned int s1, unsig
         ctl[1] = (int)s0;
         ctl[2] = (int)s1;
         ctl[3] = (int)chain0;
+        ctl[4] = 0;
     }
 }
 int launch_set_ctl(int* ctl, unsigned long long seed, unsigned int chain0, hipStream_t s) {

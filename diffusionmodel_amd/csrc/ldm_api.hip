@@ -514,8 +514,17 @@ static int run_time_path(const ldm_module* m, const float* sinemb, int rows, Une
 
 // Unet::forward body on NHWC buffers (src/main.rs:499-525; pools skipped, dropout = identity).
 // xin [B,H,W,clp]; eps_out [B,H,W,out_conv.cout] f32.
+// With `ddim` the last convolution applies the deterministic DDIM update to the sampler state instead
+// of writing eps_out (only where tapconv_can_fuse_ddim allows it).
+struct DdimFuse {
+    float* z = nullptr;          // f32 state, updated in place
+    void* zl = nullptr;          // bf16 copy of the new state
+    const float* coef = nullptr; // [steps][8]
+    int* ctl = nullptr;          // {step counter, seed low, seed high, chain0, ticket}
+};
+
 static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int B, int H, int W,
-                         const TimeVec& tv, hipStream_t st) {
+                         const TimeVec& tv, hipStream_t st, const DdimFuse* ddim = nullptr) {
     const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
     const int H2 = H / 2, W2 = W / 2, H3 = H / 4, W3 = W / 4;
     LDM_TRY(run_conv(m->down1, xin, m->clp, nullptr, 0, ub.a1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
@@ -538,6 +547,13 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
     LDM_TRY(run_conv(m->up2, u1, c2, nullptr, 0, ub.a1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_resblock(m->rb[6], ub.b1, ub.a1, ub.s1, B, H, W, tv, st));                 // up_res2 -> s1
+    if (ddim) {
+        ConvCall cc;
+        cc.in0 = ub.s1; cc.cin0 = c1; cc.out = ddim->zl; cc.B = B; cc.Hin = H; cc.Win = W;
+        cc.step_ptr = ddim->ctl;
+        cc.ddim_z = ddim->z; cc.ddim_coef = ddim->coef; cc.ddim_ticket = ddim->ctl + 4;
+        return launch_tapconv(m->out_conv, cc, st);
+    }
     LDM_TRY(run_conv(m->out_conv, ub.s1, c1, nullptr, 0, eps_out, B, H, W, ACT_NONE, nullptr, nullptr, 0, 1, st));
     return LDM_OK;
 }
@@ -567,12 +583,12 @@ struct ldm_sampler {
     void* zl = nullptr;       // bf16 copy (bf16 mode)
     float* coef = nullptr;    // [T][8]
     int* d_ts = nullptr;      // [T]
-    int* step = nullptr;      // device control words: {step counter, seed low, seed high, chain0}
+    int* step = nullptr;      // device control words: {step counter, seed low, seed high, chain0, ticket}
     float* noise = nullptr;  // NHWC f32 [steps][B,H,W,clp], allocated on first use
     size_t noise_bytes = 0;
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t exec = nullptr;
-    int g_steps = -1, g_noise = -1;
+    int g_steps = -1, g_noise = -1, g_mode = -1;
     std::vector<float> h_coef;
     std::vector<int> h_ts;
     ~ldm_sampler() {
@@ -582,8 +598,8 @@ struct ldm_sampler {
     }
 };
 
-static int sampler_step(ldm_sampler* s, bool have_noise, unsigned long long seed, unsigned int chain0, float* z_trace,
-                        float* eps_trace, int k, hipStream_t st) {
+static int sampler_step(ldm_sampler* s, int mode, bool have_noise, unsigned long long seed, unsigned int chain0,
+                        float* z_trace, float* eps_trace, int k, hipStream_t st) {
     ldm_module* m = s->unet;
     const int B = s->B, H = s->H, W = s->W;
     const size_t img = (size_t)B * m->in_ch * H * W;
@@ -591,6 +607,12 @@ static int sampler_step(ldm_sampler* s, bool have_noise, unsigned long long seed
     TimeVec tv;
     tv.table = s->ub.tvec; tv.img_stride = 0; tv.step_stride = m->tv_total; tv.step_ptr = s->step;
     const void* xin = m->dtype == LDM_BF16 ? s->zl : (const void*)s->z;
+    if (mode == LDM_DDIM && !eps_trace && m->clp == 64 && tapconv_can_fuse_ddim(m->out_conv, B, H, W)) {
+        // the scheduler update and the step advance happen in the epilogue of the last convolution
+        DdimFuse f;
+        f.z = s->z; f.zl = s->zl; f.coef = s->coef; f.ctl = s->step;
+        return run_unet_body(m, s->ub, xin, nullptr, B, H, W, tv, st, &f);
+    }
     LDM_TRY(run_unet_body(m, s->ub, xin, s->ub.eps, B, H, W, tv, st));
     if (eps_trace)
         LDM_TRY(launch_nhwc_to_nchw(s->ub.eps, LDM_F32, eps_trace + (size_t)k * img, B, m->in_ch, m->out_conv.cout, H, W, st));
@@ -838,8 +860,8 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
     }
     LDM_TRY(s->pool.alloc((void**)&s->coef, (size_t)num_time * 8 * 4));
     LDM_TRY(s->pool.alloc((void**)&s->d_ts, (size_t)num_time * 4));
-    LDM_TRY(s->pool.alloc((void**)&s->step, 16));
-    LDM_HIP(hipMemset(s->step, 0, 16));
+    LDM_TRY(s->pool.alloc((void**)&s->step, 32));
+    LDM_HIP(hipMemset(s->step, 0, 32));
     LDM_HIP(hipMemset(s->ub.tvec, 0, (size_t)num_time * unet->tv_total * 4));
     LDM_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
     // one eager forward on zeros: validates the shapes and sets every kernel's launch attributes
@@ -921,24 +943,24 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
     LDM_TRY(launch_set_ctl(s->step, seed, chain0, st));
     const bool tracing = z_trace || eps_trace;
     if (use_graph && !tracing) {
-        if (!s->exec || s->g_steps != steps || s->g_noise != (int)have_noise) {
+        if (!s->exec || s->g_steps != steps || s->g_noise != (int)have_noise || s->g_mode != mode) {
             if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
             hipGraph_t graph = nullptr;
             LDM_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = LDM_OK;
             for (int k = 0; k < steps && rc == LDM_OK; ++k)
-                rc = sampler_step(s, have_noise, seed, chain0, nullptr, nullptr, k, s->cap_stream);
+                rc = sampler_step(s, mode, have_noise, seed, chain0, nullptr, nullptr, k, s->cap_stream);
             hipError_t e = hipStreamEndCapture(s->cap_stream, &graph);
             if (rc != LDM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LDM_HIP(e);
             e = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             LDM_HIP(e);
-            s->g_steps = steps; s->g_noise = (int)have_noise;
+            s->g_steps = steps; s->g_noise = (int)have_noise; s->g_mode = mode;
         }
         LDM_HIP(hipGraphLaunch(s->exec, st));
     } else {
-        for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, have_noise, seed, chain0, z_trace, eps_trace, k, st));
+        for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, mode, have_noise, seed, chain0, z_trace, eps_trace, k, st));
     }
     LDM_TRY(launch_nhwc_to_nchw(s->z, LDM_F32, z_out, B, m->in_ch, m->clp, H, W, st));
     return LDM_OK;

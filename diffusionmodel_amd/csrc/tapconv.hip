@@ -47,6 +47,9 @@
 #ifndef TAPCONV_NO_WS64
 #define TAPCONV_NO_WS64 0
 #endif
+#ifndef TAPCONV_WS_XD
+#define TAPCONV_WS_XD 3
+#endif
 #ifndef TAPCONV_RING_L1
 #define TAPCONV_RING_L1 3
 #endif
@@ -86,28 +89,34 @@ struct TapConvArgs {
     int act, out_f32;
     int t_img_stride, t_step_stride;
     long w_phase_stride;         // bytes
-    unsigned long long* dbg;     // cycle stamps (diagnostic builds with TAPCONV_STAMP only), else null
+    float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
+    const float* sched_coef;     // its coefficient table [steps][8]
+    int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
 };
 
-#ifdef TAPCONV_STAMP
-#define STAMP(i)                                                                                   \
-    do {                                                                                           \
-        if (a.dbg && blockIdx.x == 0 && wave == 0) {                                               \
-            unsigned long long t_;                                                                 \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-            if (lane == 0 && (i) < 64) a.dbg[(i)] = t_;                                             \
-        }                                                                                          \
-    } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU.  f32 mode divides exactly; bf16 mode multiplies by the hardware reciprocal (1 ulp of f32, far
+// below the bf16 rounding of the result): the IEEE division costs about as many issue cycles per
+// output element as all the MFMAs that produced it at the 64-channel level.
+template <bool EXACT>
+__device__ __forceinline__ float silu_f(float v) {
+    const float d = 1.0f + __expf(-v);
+    if constexpr (EXACT) return v / d;
+    else return v * __builtin_amdgcn_rcpf(d);
+}
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two f32 -> packed bf16 pair (one v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
 // by-value helper: bit_cast applied directly to a vector-element expression reads element 0
 __device__ __forceinline__ float u2f(unsigned int u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned int f2u(float f) { return __builtin_bit_cast(unsigned int, f); }
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         if (a.res) { v0 += r0[i]; v1 += r1[i]; }
         if (a.act == ACT_SILU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v0[q] = silu_f(v0[q]); v1[q] = silu_f(v1[q]); }
+            for (int q = 0; q < 4; ++q) { v0[q] = silu_f<sizeof(T) == 4>(v0[q]); v1[q] = silu_f<sizeof(T) == 4>(v1[q]); }
         } else if (a.act == ACT_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
@@ -440,10 +449,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             }
         } else {
             u32x4 o;
-            o[0] = (unsigned int)f2bf(v0[0]) | ((unsigned int)f2bf(v0[1]) << 16);
-            o[1] = (unsigned int)f2bf(v0[2]) | ((unsigned int)f2bf(v0[3]) << 16);
-            o[2] = (unsigned int)f2bf(v1[0]) | ((unsigned int)f2bf(v1[1]) << 16);
-            o[3] = (unsigned int)f2bf(v1[2]) | ((unsigned int)f2bf(v1[3]) << 16);
+            o[0] = pack2(v0[0], v0[1]);
+            o[1] = pack2(v0[2], v0[3]);
+            o[2] = pack2(v1[0], v1[1]);
+            o[3] = pack2(v1[2], v1[3]);
             if (st) *(u32x4*)(a.out + eo[i] * 2) = o;
         }
     }
@@ -452,19 +461,43 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
 // ---------------------------------------------------------------------------------------------
 // Weight-stationary persistent variant: conv3x3 stride 1, 64 -> 64 channels, bf16 (the 64-channel
 // level of the UNet: down1, down_res1, up_res2, out_conv).  At that level a launch moves 67-100 MB
-// through HBM for 19 GFLOP; per tile the generic kernel spends more time on its DMA steps, barriers
-// and epilogue than on MFMAs.  Here a workgroup of 4 waves walks over 8x16-pixel tiles; every wave
-// keeps the weight fragments of its 32 output channels (18 half steps x 2 fragments = 144 registers)
-// in registers for the whole kernel, so per tile only the halo crosses LDS (double-buffered: the
-// next tile's halo is DMA'd while this tile computes), there is ONE barrier per tile, and the epilogue
-// needs no LDS: a lane swaps one accumulator with lane^16 and then owns 8 consecutive channels of a
-// pixel (16-byte stores).  Two workgroups share a CU and drift apart, so one computes while the other
-// is in its memory phases.
+// through HBM for 19 GFLOP; per tile the generic kernel spends more time on its DMA steps, barriers and
+// epilogue than on MFMAs.  Here a workgroup of 4 waves walks over 8x16-pixel tiles; every wave keeps
+// the weight fragments of its 32 output channels (18 half steps x 2 fragments = 144 registers) in
+// registers for the whole kernel, so per tile only the halo crosses LDS (double-buffered) and there is
+// ONE barrier per tile.
+//
+// A wave computes its 4 rows of a tile as two halves of 2 rows (72 MFMAs each).  Everything else is
+// spread over the MFMAs of a half, one small piece per half step, so that no wave ever has a phase
+// without MFMAs and the workgroups of the chip (which start together and do equal work) do not all
+// store at the same moment:
+//   * the DMA pieces of the NEXT tile's halo (3 per half),
+//   * the loads the epilogue of THIS half needs (residual rows, or the rows of the sampler state),
+//   * the whole epilogue of the PREVIOUS half (its 16 accumulator registers are kept): lane swap,
+//     bias, residual, SiLU, time vector, packing and the stores.
+// The epilogue needs no LDS: v_permlane16_swap exchanges the odd 16-lane rows of one accumulator with
+// the even rows of the other, after which a lane owns 8 consecutive channels of a pixel.
+//
+// Modes (the epilogue shapes the UNet uses at this level):
+//   WS_PLAIN     out = conv + bias
+//   WS_SILU_TV   out = silu(conv + bias) + time vector
+//   WS_SILU_RES  out = silu(conv + bias + residual)
+//   WS_DDIM      conv + bias is the predicted noise e of the sampler; the deterministic DDIM update
+//                z' = ((z - e*s1m)/sa)*c1 + e*c2 is applied to the f32 state in place and its bf16
+//                copy (the next UNet input) is written; e itself never goes to memory.
 // ---------------------------------------------------------------------------------------------
+template <bool B> struct BoolC { static constexpr bool value = B; };
+enum { WS_PLAIN = 0, WS_SILU_TV = 1, WS_SILU_RES = 2, WS_DDIM = 3 };
+
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs a) {
+    constexpr bool RES = MODE == WS_SILU_RES, TV = MODE == WS_SILU_TV, SILU = RES || TV, DDIM = MODE == WS_DDIM;
     constexpr int TH = 8, HW = 18, HP = 10 * 18, NG = (HP + 31) / 32;
     constexpr int HPLANE = NG * 1024, HALO_BYTES = 4 * HPLANE;       // 4 waves: piece q of wave w = (group q, plane w)
-    constexpr int WN = 2, MF = 4, NF = 2, KS = 18;
+    constexpr int WN = 2, NF = 2, KS = 18, HR = 2;                   // HR rows per half
+    constexpr int NLD = DDIM ? 2 * HR : HR;                          // epilogue input loads per half
+    constexpr int XD = TAPCONV_WS_XD;                                // depth of the X fragment register ring
+    static_assert(NG == 6, "three halo pieces per half");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -474,17 +507,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     const char* zero = (const char*)g_zero16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
-    STAMP(0);
-#ifdef TAPCONV_WS_STAGGER
-    // Workgroups that start together stay in phase (all compute, then all store); delaying the second
-    // half of the grid by about half a tile period lets one workgroup's memory phase overlap the
-    // other's MFMA phase.  Speed only.
-    if (blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < TAPCONV_WS_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-#endif
+    int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
 
     // this wave's 32 output channels of every (tap, half), straight from the packed weights (L2)
     u32x4 wreg[KS][NF];
@@ -503,140 +526,224 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         const int hy = hp / HW, hx = hp - hy * HW;
         hyx[q] = hp < HP ? (hy << 8 | hx) : -1;
     }
-    auto issue_halo = [&](int t, int buf) {
-        const int img = t / tiles_per_img;
-        const int trem = t - img * tiles_per_img;
-        const int iy0 = (trem / a.tiles_x) * TH - 1, ix0 = (trem % a.tiles_x) * 16 - 1;
-        const char* base = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
-        const unsigned hb = buf * HALO_BYTES + wave * HPLANE;
-#pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            const int iy = iy0 + (hyx[q] >> 8), ix = ix0 + (hyx[q] & 255);
-            const bool ok = hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            const char* src = ok ? base + (size_t)(iy * a.Win + ix) * 128 : zero;
-            glds16(src, smem + hb + q * 1024);
-        }
+    // origin of a tile's window and the lane's source base; a tile past the end reads the zero page
+    const char* hbase;
+    int hiy0, hix0;
+    bool hlive;
+    auto halo_origin = [&](int t) {
+        hlive = t < a.ntiles;
+        const int tt = hlive ? t : 0;
+        const int img = tt / tiles_per_img;
+        const int trem = tt - img * tiles_per_img;
+        hiy0 = (trem / a.tiles_x) * TH - 1;
+        hix0 = (trem % a.tiles_x) * 16 - 1;
+        hbase = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
     };
-    issue_halo(tile, 0);
+    auto halo_piece = [&](int q, int buf) {
+        const int iy = hiy0 + (hyx[q] >> 8), ix = hix0 + (hyx[q] & 255);
+        const bool ok = hlive && hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * 128 : zero;
+        glds16(src, smem + buf * HALO_BYTES + wave * HPLANE + q * 1024);
+    };
+    halo_origin(tile);
+#pragma unroll
+    for (int q = 0; q < NG; ++q) halo_piece(q, 0);
 
     // epilogue constants: after the lane swap this lane owns channels co .. co+7 of pixel column l15
-    const unsigned hlane = (g >> 1) * HPLANE + ((wm * MF) * HW + l15) * 32 + (g & 1) * 16;
+    const unsigned hlane = (g >> 1) * HPLANE + ((wm * 2 * HR) * HW + l15) * 32 + (g & 1) * 16;
     const int co = wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
-    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
     const int step = a.step_ptr ? *a.step_ptr : 0;
-    const int nstore = a.out_f32 ? 2 * MF : MF;
+    const size_t erow = (size_t)a.Wout * 64;
+    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+    float k_s1m = 0.f, k_rsa = 0.f, k_c1 = 0.f, k_c2 = 0.f;
+    if (DDIM) {
+        const float* cf = a.sched_coef + (size_t)step * 8;
+        const bool last = cf[6] != 0.f;
+        k_s1m = cf[1];
+        k_rsa = 1.0f / cf[0];
+        k_c1 = last ? 1.0f : cf[2];
+        k_c2 = last ? 0.0f : cf[3];
+    }
 
-    int buf = 0;
-    bool first = true;
-    STAMP(1);
-    int sidx = 2;
-    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
-        // this tile's halo has landed; only the previous epilogue's stores may still be in flight
-        if (first) wait_vmcnt<0>();
-        else if (nstore == MF) wait_vmcnt<MF>();
-        else wait_vmcnt<2 * MF>();
-        first = false;
-        __builtin_amdgcn_s_barrier();      // also: every wave is done reading the other halo buffer
-        STAMP(sidx); ++sidx;
-        const int next = tile + gridDim.x;
-        if (next < a.ntiles && !(TAPCONV_ABLATE & 16)) issue_halo(next, buf ^ 1);
-        STAMP(sidx); ++sidx;
+    // state handed from one half to the next: the finished accumulators, the loads their epilogue
+    // needs, the time vector and the element offset of their first row
+    f32x4 accP[NF][HR];
+    u32x4 ldP[NLD];
+    f32x4 tP0 = {0.f, 0.f, 0.f, 0.f}, tP1 = {0.f, 0.f, 0.f, 0.f};
+    size_t eP = 0;
+    f32x4 v0, v1;          // the row that is passing through the epilogue slices
 
-        f32x4 acc[NF][MF];
+    // Slice s (0..17) of the previous half's epilogue: row s/9; step 0 swaps lanes and adds bias and
+    // residual, steps 1..7 apply the activation to the 8 values, step 8 finishes and stores.
+    auto epi_slice = [&](int s18) {
+        const int j = s18 / 9, s = s18 % 9;
+        if (s == 0) {
+            // lanes of odd 16-lane rows take the partner's fragment 1 channels, even rows keep
+            // fragment 0 and receive the partner's: v0 | v1 = 8 consecutive channels
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* hp0 = smem + buf * HALO_BYTES + hlane;
-        u32x4 xf[2][MF];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) xf[0][mf] = *(const u32x4*)(hp0 + mf * (HW * 32));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-                const int t = (ks + 1) >> 1, kk = (ks + 1) & 1;
-                const int off = kk * 2 * HPLANE + ((t / 3) * HW + (t % 3)) * 32;
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) xf[(ks + 1) & 1][mf] = *(const u32x4*)(hp0 + off + mf * (HW * 32));
+            for (int q = 0; q < 4; ++q) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[1][j][q]), false, false);
+                v0[q] = u2f(sw[0]);
+                v1[q] = u2f(sw[1]);
             }
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) {
-                    if constexpr (TAPCONV_ABLATE & 1)
-                        asm volatile("" ::"v"(wreg[ks][nf]), "v"(xf[ks & 1][mf]));
-                    else
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[ks & 1][mf]),
-                            acc[nf][mf], 0, 0, 0);
-                }
-            if (ks + 1 < KS && !(TAPCONV_ABLATE & 1)) {
-#pragma unroll
-                for (int r = 0; r < MF; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-        }
-        STAMP(sidx); ++sidx;
-
-        // ---- epilogue: v = acc + bias (+ residual) -> activation -> (+ time vector) -> store ----
-        const int img = tile / tiles_per_img;
-        const int trem = tile - img * tiles_per_img;
-        const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
-        const float* tv = a.tvec ? a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co : nullptr;
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-        if (tv) { t0 = *(const f32x4*)tv; t1 = *(const f32x4*)(tv + 4); }
-        const size_t e0 = (((size_t)img * a.Hout + y0 + wm * MF) * a.Wout + x0 + l15) * 64 + co;
-        const size_t erow = (size_t)a.Wout * 64;
-        u32x4 rr[MF];
-        if (a.res) {
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) rr[mf] = *(const u32x4*)(a.res + (e0 + mf * erow) * 2);
-        }
-        const bool odd = g & 1;
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            // lanes g and g^1 swap one accumulator: g even keeps channel fragment 0 and receives the
-            // partner's fragment 0 (the next 4 channels); g odd keeps fragment 1 and receives fragment 1
-            const f32x4 send = odd ? acc[0][mf] : acc[1][mf];
-            f32x4 recv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) recv[q] = __shfl_xor(send[q], 16);
-            f32x4 v0 = (odd ? recv : acc[0][mf]) + b0;
-            f32x4 v1 = (odd ? acc[1][mf] : recv) + b1;
-            if (a.res) {
-                const unsigned int u0 = rr[mf][0], u1 = rr[mf][1], u2 = rr[mf][2], u3 = rr[mf][3];
+            v0 += b0;
+            v1 += b1;
+            if (RES) {
+                const unsigned int u0 = ldP[j][0], u1 = ldP[j][1], u2 = ldP[j][2], u3 = ldP[j][3];
                 v0[0] += bf2f((bf16_t)(u0 & 0xffffu)); v0[1] += bf2f((bf16_t)(u0 >> 16));
                 v0[2] += bf2f((bf16_t)(u1 & 0xffffu)); v0[3] += bf2f((bf16_t)(u1 >> 16));
                 v1[0] += bf2f((bf16_t)(u2 & 0xffffu)); v1[1] += bf2f((bf16_t)(u2 >> 16));
                 v1[2] += bf2f((bf16_t)(u3 & 0xffffu)); v1[3] += bf2f((bf16_t)(u3 >> 16));
             }
-            if (a.act == ACT_SILU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v0[q] = silu_f(v0[q]); v1[q] = silu_f(v1[q]); }
-            } else if (a.act == ACT_RELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+        } else if (s < 8) {
+            if (SILU) {
+                if (s == 1) { v0[0] = silu_f<false>(v0[0]); v0[1] = silu_f<false>(v0[1]); }
+                if (s == 2) v0[2] = silu_f<false>(v0[2]);
+                if (s == 3) v0[3] = silu_f<false>(v0[3]);
+                if (s == 4) v1[0] = silu_f<false>(v1[0]);
+                if (s == 5) v1[1] = silu_f<false>(v1[1]);
+                if (s == 6) v1[2] = silu_f<false>(v1[2]);
+                if (s == 7) v1[3] = silu_f<false>(v1[3]);
             }
-            v0 += t0;
-            v1 += t1;
-            // every store is issued (the launcher only picks this kernel when tiles cover the image
-            // exactly), so each wave has the same number of stores in flight for the counted wait above
-            const size_t eo = e0 + mf * erow;
-            if (a.out_f32) {
-                *(f32x4*)(a.out + eo * 4) = v0;
-                *(f32x4*)(a.out + eo * 4 + 16) = v1;
-            } else {
-                u32x4 o;
-                o[0] = (unsigned int)f2bf(v0[0]) | ((unsigned int)f2bf(v0[1]) << 16);
-                o[1] = (unsigned int)f2bf(v0[2]) | ((unsigned int)f2bf(v0[3]) << 16);
-                o[2] = (unsigned int)f2bf(v1[0]) | ((unsigned int)f2bf(v1[1]) << 16);
-                o[3] = (unsigned int)f2bf(v1[2]) | ((unsigned int)f2bf(v1[3]) << 16);
-                if (!(TAPCONV_ABLATE & 8) || v0[0] == 12345.678f) *(u32x4*)(a.out + eo * 2) = o;
+        } else {
+            const size_t eo = eP + j * erow;
+            if (TV) { v0 += tP0; v1 += tP1; }
+            if (DDIM) {
+                f32x4 z0, z1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    z0[q] = u2f(ldP[2 * j][q]);
+                    z1[q] = u2f(ldP[2 * j + 1][q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    z0[q] = ((z0[q] - v0[q] * k_s1m) * k_rsa) * k_c1 + v0[q] * k_c2;
+                    z1[q] = ((z1[q] - v1[q] * k_s1m) * k_rsa) * k_c1 + v1[q] * k_c2;
+                }
+                *(f32x4*)(a.sched_z + eo) = z0;
+                *(f32x4*)(a.sched_z + eo + 4) = z1;
+                v0 = z0;
+                v1 = z1;
+            }
+            u32x4 o;
+            o[0] = pack2(v0[0], v0[1]);
+            o[1] = pack2(v0[2], v0[3]);
+            o[2] = pack2(v1[0], v1[1]);
+            o[3] = pack2(v1[2], v1[3]);
+            *(u32x4*)(a.out + eo * 2) = o;
+        }
+    };
+
+    int buf = 0;
+    int img = 0;
+    size_t e0 = 0;
+
+    auto tile_top = [&]() {
+        // this tile's halo has landed (issued during the previous tile) and every wave is done
+        // reading the other halo buffer, which the next tile's pieces overwrite from here on
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        halo_origin(tile + (int)gridDim.x);
+        img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
+        e0 = (((size_t)img * a.Hout + y0 + wm * 2 * HR) * a.Wout + x0 + l15) * 64 + co;
+    };
+
+    auto do_half = [&](auto half_tag, auto epi_tag) {
+        constexpr int HALF = decltype(half_tag)::value ? 1 : 0;
+        constexpr bool EPI = decltype(epi_tag)::value;
+        const size_t eC = e0 + HALF * HR * erow;
+        f32x4 acc[NF][HR];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ldC[NLD];
+        f32x4 tC0 = {0.f, 0.f, 0.f, 0.f}, tC1 = {0.f, 0.f, 0.f, 0.f};
+        const char* hp0 = smem + buf * HALO_BYTES + hlane + HALF * HR * (HW * 32);
+        // X fragments: a register ring XD half steps deep (LDS latency is longer than the 4 MFMAs of one)
+        auto xoff = [&](int k) {
+            const int t = k >> 1, kk = k & 1;
+            return kk * 2 * HPLANE + ((t / 3) * HW + (t % 3)) * 32;
+        };
+        u32x4 xf[XD][HR];
+#pragma unroll
+        for (int k = 0; k < XD - 1; ++k)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) xf[k][r] = *(const u32x4*)(hp0 + xoff(k) + r * (HW * 32));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + XD - 1 < KS) {
+#pragma unroll
+                for (int r = 0; r < HR; ++r)
+                    xf[(ks + XD - 1) % XD][r] = *(const u32x4*)(hp0 + xoff(ks + XD - 1) + r * (HW * 32));
+            }
+            // memory work, one operation per half step
+            if (ks < 3) halo_piece(HALF * 3 + ks, buf ^ 1);
+            if (RES && ks >= 4 && ks < 4 + HR)
+                ldC[ks - 4] = *(const u32x4*)(a.res + (eC + (ks - 4) * erow) * 2);
+            if (DDIM && ks >= 4 && ks < 4 + 2 * HR)
+                ldC[ks - 4] = *(const u32x4*)(a.sched_z + eC + ((ks - 4) >> 1) * erow + ((ks - 4) & 1) * 4);
+            if (TV && ks == 4) {
+                const float* tv = a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co;
+                tC0 = *(const f32x4*)tv;
+                tC1 = *(const f32x4*)(tv + 4);
+            }
+            if (EPI) epi_slice(ks);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < HR; ++r)
+                    acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[ks % XD][r]),
+                        acc[nf][r], 0, 0, 0);
+            if (ks + XD - 1 < KS) {
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
-        STAMP(sidx); ++sidx;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) accP[nf][r] = acc[nf][r];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) ldP[i] = ldC[i];
+        tP0 = tC0;
+        tP1 = tC1;
+        eP = eC;
+    };
+
+    tile_top();
+    do_half(BoolC<false>{}, BoolC<false>{});
+    do_half(BoolC<true>{}, BoolC<true>{});
+    tile += gridDim.x;
+    buf ^= 1;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        tile_top();
+        do_half(BoolC<false>{}, BoolC<true>{});
+        do_half(BoolC<true>{}, BoolC<true>{});
+    }
+    // the last half's epilogue
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) epi_slice(s);
+
+    if (DDIM && a.sched_ticket) {
+        // Advance the sampler's step counter once per launch.  Every wave read the counter before its
+        // first tile, and a workgroup takes its ticket only after all its waves arrived here, so the
+        // workgroup that draws the last ticket knows that nobody will read the old value any more.
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(a.sched_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (int)gridDim.x - 1) {
+                __hip_atomic_store(a.sched_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(const_cast<int*>(a.step_ptr), step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -687,6 +794,7 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
     return 4;
 }
 
+template <int MODE>
 static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
     static int ncu = 0;
     if (ncu == 0) {
@@ -700,23 +808,38 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
     a.nblk_n = 1;
     const size_t lds = 2 * 6 * 4096;                 // two halo buffers of 10x18 pixels
     const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-#ifdef TAPCONV_STAMP
-    if (const char* e = getenv("LDM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 16);
-#endif
-    hipLaunchKernelGGL(tapconv_ws64_kernel, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(tapconv_ws64_kernel<MODE>, dim3(grid), dim3(256), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
+}
+
+// The shapes the weight-stationary kernel serves: 64 -> 64 channels, bf16, exact 8x16 tiling, at least
+// one tile per workgroup slot of the chip.
+static bool ws64_shape(const PackedConv& pc, const TapConvArgs& a) {
+    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 &&
+           a.Hg % 8 == 0 && a.Wg % 16 == 0 && (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
+}
+
+bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
+    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && pc.cin == 64 && pc.cout == 64 && H % 8 == 0 && W % 16 == 0 &&
+           (long)(H / 8) * (W / 16) * B >= 512 && !TAPCONV_NO_WS64;
 }
 
 template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     const int bn = (a.cout % 128 == 0) ? 128 : 64;
     if constexpr (sizeof(T) == 2) {
-        // 64 -> 64 channels, exact 16x16 tiling, at least one tile per CU: weight-stationary kernel
-        if (pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 && a.Hg % 8 == 0 && a.Wg % 16 == 0 &&
-            (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512 && !TAPCONV_NO_WS64)
-            return launch_ws64(a, stream);
+        if (ws64_shape(pc, a)) {
+            if (a.sched_z) {
+                if (a.act == ACT_NONE && !a.res && !a.tvec) return launch_ws64<WS_DDIM>(a, stream);
+            } else if (!a.out_f32) {
+                if (a.act == ACT_NONE && !a.res && !a.tvec) return launch_ws64<WS_PLAIN>(a, stream);
+                if (a.act == ACT_SILU && !a.res && a.tvec) return launch_ws64<WS_SILU_TV>(a, stream);
+                if (a.act == ACT_SILU && a.res && !a.tvec) return launch_ws64<WS_SILU_RES>(a, stream);
+            }
+        }
     }
+    if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
     const int nblk_n = a.cout / bn;
     const long tx = (a.Wg + 15) / 16;
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;
@@ -782,6 +905,8 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     a.ntaps = pc.ntaps;
     a.act = cc.act; a.out_f32 = (pc.dtype == LDM_F32) ? 1 : cc.out_f32;
     a.t_img_stride = cc.t_img_stride; a.t_step_stride = cc.t_step_stride;
+    a.sched_z = cc.ddim_z; a.sched_coef = cc.ddim_coef; a.sched_ticket = cc.ddim_ticket;
+    LDM_REQUIRE(!cc.ddim_z || (cc.ddim_coef && cc.step_ptr), "fused DDIM update needs the coefficient table and the step counter");
     a.w_phase_stride = (long)(pc.cin / ck) * pc.ntaps * pc.cout * 128;
     if (pc.dtype == LDM_BF16) return launch_typed<bf16_t>(pc, cc, a, stream);
     return launch_typed<float>(pc, cc, a, stream);
