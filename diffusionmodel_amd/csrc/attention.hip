@@ -33,8 +33,8 @@ __device__ __forceinline__ unsigned int at_pack2(float a, float b) {
            ((unsigned int)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
 }
 
-template <typename T, int D, int QF, int KF>
-__global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restrict__ qkv, char* __restrict__ out, int N,
+template <typename T, int D, int QF, int KF, int MINB>
+__global__ __launch_bounds__(256, MINB) void attention_kernel(const char* __restrict__ qkv, char* __restrict__ out, int N,
                                                            float scale_log2e) {
     constexpr int ES = sizeof(T);
     constexpr int RB = D * ES;              // bytes of one q / k / v row
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
     constexpr int QB = 4 * QF * 16;
     static_assert(ES == 4 || KF == 2, "bf16 PV uses K = 32 keys per MFMA");
     static_assert(RB >= 256, "rows shorter than 16 pieces are not swizzled correctly");
+    constexpr float RESCALE_LOG2 = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
 
         // ---- online soft-max: lane holds keys kf*16 + g*4 + r of query column l15 --------
         float alpha[QF];
+        bool moved = false;
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             float mx = -1e30f;
@@ -147,8 +149,14 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qf], mx);
-            alpha[qf] = exp2f(mrun[qf] - mnew);
+            // Lazy reference: the running reference m only moves when a tile's maximum exceeds it by more
+            // than 2^RESCALE_LOG2; until then p = 2^(s - m) may be as large as that factor, which f32
+            // sums and bf16 P values hold without loss, and O needs no rescaling (the common case
+            // after the first tiles).  The first tile always moves it (m starts at -1e30, O is 0).
+            const bool move = mx > mrun[qf] + RESCALE_LOG2;
+            const float mnew = move ? mx : mrun[qf];
+            alpha[qf] = move ? exp2f(mrun[qf] - mnew) : 1.0f;
+            moved |= move;
             mrun[qf] = mnew;
             float rs = 0.f;
 #pragma unroll
@@ -161,10 +169,12 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
                 }
             lrun[qf] = lrun[qf] * alpha[qf] + rs;   // per-lane partial; the 4 key groups are summed at the end
         }
+        if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {      // wave-uniform
 #pragma unroll
-        for (int df = 0; df < DF; ++df)
+            for (int df = 0; df < DF; ++df)
 #pragma unroll
-            for (int qf = 0; qf < QF; ++qf) oacc[df][qf] *= alpha[qf];
+                for (int qf = 0; qf < QF; ++qf) oacc[df][qf] *= alpha[qf];
+        }
 
         // ---- O^T += V^T P^T -----------------------------------------------------------------
         if constexpr (ES == 2) {
@@ -240,13 +250,13 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const char* __restric
     }
 }
 
-template <typename T, int D, int QF, int KF>
+template <typename T, int D, int QF, int KF, int MINB = 1>
 static int launch_attn_cfg(const void* qkv, void* out, int B, int N, hipStream_t stream) {
     constexpr int TILE = KF * 16 * D * (int)sizeof(T);
     constexpr int QB = 4 * QF * 16;
     const size_t lds = (size_t)4 * TILE;
     static_assert(4 * TILE <= 160 * 1024, "LDS budget");
-    auto kern = attention_kernel<T, D, QF, KF>;
+    auto kern = attention_kernel<T, D, QF, KF, MINB>;
     static bool attr_set = false;
     if (!attr_set) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -265,7 +275,10 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
     if (dtype == LDM_BF16) {
         switch (C) {
             case 128: return launch_attn_cfg<bf16_t, 128, 2, 2>(qkv, out, B, N, stream);
-            case 256: return launch_attn_cfg<bf16_t, 256, 2, 2>(qkv, out, B, N, stream);
+            case 256:
+                // 16 queries per wave while that still leaves every CU a workgroup; O then stays in VGPRs
+                if ((long)B * ((N + 127) / 128) < 256) return launch_attn_cfg<bf16_t, 256, 1, 2, 2>(qkv, out, B, N, stream);
+                return launch_attn_cfg<bf16_t, 256, 2, 2>(qkv, out, B, N, stream);
             case 512: return launch_attn_cfg<bf16_t, 512, 1, 2>(qkv, out, B, N, stream);
         }
     } else {

@@ -316,31 +316,42 @@ int launch_nhwc_to_nchw(const void* in, int in_dtype, float* out, int B, int C, 
 // Time path (tiny): out[r, n] = act(sum_k in[r,k] * W[k,n] + b[n]).  One thread per output column,
 // 8 rows per block kept in LDS; W rows are read coalesced.  f32 FMA chain in k order.
 // ---------------------------------------------------------------------------------------------
+// A workgroup owns 4 rows x 16 output columns and splits K over 16 thread slices (slice s takes
+// k = s, s+16, ...), so that even the [50, 2048] x [2048, 256] Linear of the time path fills >100
+// workgroups with short dependent chains; the slices are summed through LDS in a fixed order.
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ out, int rows,
                                                          int K, int N, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* xs = (float*)smem_raw;   // [8][K]
-    const int r0 = blockIdx.y * 8;
-    const int nr = min(8, rows - r0);
-    for (int k = threadIdx.x; k < nr * K; k += 256) xs[k] = in[(size_t)r0 * K + k];
+    float* xs = (float*)smem_raw;                 // [4][K]
+    float* red = xs + 4 * K;                      // [16 slices][4 rows][16 columns]
+    const int r0 = blockIdx.y * 4;
+    const int nr = min(4, rows - r0);
+    for (int k = threadIdx.x; k < 4 * K; k += 256) xs[k] = k < nr * K ? in[(size_t)r0 * K + k] : 0.f;
     __syncthreads();
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float acc[8];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    float acc[4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float w = W[(size_t)k * N + n];
+    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+    if (n < N) {
+#pragma unroll 4
+        for (int k = sl; k < K; k += 16) {
+            const float w = W[(size_t)k * N + n];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (r < nr) acc[r] = fmaf(xs[r * K + k], w, acc[r]);
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(xs[r * K + k], w, acc[r]);
+        }
     }
-    const float bias = b ? b[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < nr) {
-            float v = acc[r] + bias;
+    for (int r = 0; r < 4; ++r) red[(sl * 4 + r) * 16 + c] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int r = threadIdx.x >> 4;
+        float v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) v += red[(s2 * 4 + r) * 16 + c];
+        if (n < N && r < nr) {
+            v += b ? b[n] : 0.f;
             if (act == ACT_RELU) v = fmaxf(v, 0.f);
             else if (act == ACT_SILU) v = v / (1.0f + expf(-v));
             out[(size_t)(r0 + r) * N + n] = v;
@@ -351,9 +362,10 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 int launch_linear_f32(const float* in, const float* W, const float* b, float* out, int rows, int K, int N, int act,
                       hipStream_t s) {
     LDM_REQUIRE(in && W && out && rows > 0 && K > 0 && N > 0, "bad arguments");
-    LDM_REQUIRE((size_t)8 * K * 4 <= 64 * 1024, "K too large for the time-path Linear");
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((rows + 7) / 8));
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), (size_t)8 * K * 4, s, in, W, b, out, rows, K, N, act);
+    const size_t lds = (size_t)4 * K * 4 + 16 * 4 * 16 * 4;
+    LDM_REQUIRE(lds <= 64 * 1024, "K too large for the time-path Linear");
+    dim3 grid((unsigned)((N + 15) / 16), (unsigned)((rows + 3) / 4));
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), lds, s, in, W, b, out, rows, K, N, act);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

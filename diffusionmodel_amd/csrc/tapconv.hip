@@ -50,6 +50,9 @@
 #ifndef TAPCONV_WS_XD
 #define TAPCONV_WS_XD 3
 #endif
+#ifndef TAPCONV_1X1_RING
+#define TAPCONV_1X1_RING 3
+#endif
 #ifndef TAPCONV_RING_L1
 #define TAPCONV_RING_L1 3
 #endif
@@ -845,22 +848,27 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;
     const int nph = pc.nphase;
     if (pc.kind == CONV3x3_S2) {
+        // one input chunk: a two-deep weight ring leaves room for two workgroups per CU, which hides the
+        // halo prologue of one behind the MFMAs of the other (32 -> 24 us at 64 -> 128 channels)
+        if (bn == 128 && a.nch0 == 1) return launch_cfg<T, 4, 128, 2, 2, 2, 3, 9, 2, 2>(a, nph, stream);
         if (bn == 128) return launch_cfg<T, 4, 128, 2, 2, 2, 3, 9, 1>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 2, 3, 9, 1>(a, nph, stream);
     }
     if (pc.kind == CONV1x1) {
-        const int th = pick_th(t16, t8, nblk_n, nph, 256, true);
+        int th = pick_th(t16, t8, nblk_n, nph, 256, true);
+        if (bn == 64 && th > 8) th = 8;       // memory-bound: two workgroups per CU beat the taller tile
         if (bn == 128) {
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 1, 1, 2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 1, 1, 1>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 1, 1, 1>(a, nph, stream);
         }
         if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 1, 1, 2>(a, nph, stream);
-        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
+        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 1, 2, TAPCONV_1X1_RING>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
     }
     // 3x3-window kinds: conv3x3 stride 1 (9 taps) and the convT phases (4 taps)
-    const int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true);
+    int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true);
+    if (pc.kind == CONVT4x4_S2 && bn == 64 && th > 8) th = 8;   // two workgroups per CU (LDS) beat the taller tile
     if (pc.kind == CONV3x3_S1) {
         if (bn == 128) {
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);

@@ -113,6 +113,27 @@ def test_attention(A, O, dtype, C, B, H, W):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("spike_at", [3, 200, 253])
+def test_attention_running_max_jump(A, O, dtype, spike_at):
+    """One token far larger than the rest: its key dominates every query's soft-max, so the running
+    reference of the online soft-max jumps by more than the lazy-rescale threshold at the tile that
+    holds the token (first, late and last tile) and the accumulated output must be rescaled there."""
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    C, B, H, W = 256, 2, 16, 16
+    w = synthetic_from_shapes(attention_param_shapes(C), 6)
+    torch.manual_seed(20 + spike_at)
+    x = torch.randn(B, C, H, W)
+    x[:, :, spike_at // W, spike_at % W] *= 12.0
+    ref = O.attention({"m." + k: v for k, v in w.items()}, "m", x)
+    _say(f"attention spike {dtype} at token {spike_at}")
+    got = A.Attention(C, dtype=dtype, weights=w)(x.cuda())
+    torch.cuda.synchronize()
+    e_branch = rel_err(got - x.cuda(), ref - x)
+    _say(f"  branch rel_err={e_branch:.3e}")
+    assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
+
+
 # ---- full UNet forward --------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("Cl,B,S", [(64, 4, 4), (64, 2, 16), (8, 2, 8), (64, 1, 64)])
