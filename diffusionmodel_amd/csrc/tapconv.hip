@@ -37,6 +37,7 @@
 // per 16-byte fragment, with the K permutation applied identically to both operands.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
 // the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA.
@@ -498,7 +499,10 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     constexpr int TH = 8, HW = 18, HP = 10 * 18, NG = (HP + 31) / 32;
     constexpr int HPLANE = NG * 1024, HALO_BYTES = 4 * HPLANE;       // 4 waves: piece q of wave w = (group q, plane w)
     constexpr int WN = 2, NF = 2, KS = 18, HR = 2;                   // HR rows per half
-    constexpr int NLD = DDIM ? 2 * HR : HR;                          // epilogue input loads per half
+    // epilogue inputs of a half (residual rows, rows of the sampler state, or the time vector): 1-KiB
+    // LDS-DMA pieces per wave, 16 bytes per lane, read back by the same lane
+    constexpr int NLDG = RES ? HR : (DDIM ? 2 * HR : (TV ? 2 : 0));
+    constexpr int NST = DDIM ? 3 : 1;                                // stores per epilogue row
     constexpr int XD = TAPCONV_WS_XD;                                // depth of the X fragment register ring
     static_assert(NG == 6, "three halo pieces per half");
 
@@ -571,9 +575,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     // state handed from one half to the next: the finished accumulators, the loads their epilogue
     // needs, the time vector and the element offset of their first row
     f32x4 accP[NF][HR];
-    u32x4 ldP[NLD];
-    f32x4 tP0 = {0.f, 0.f, 0.f, 0.f}, tP1 = {0.f, 0.f, 0.f, 0.f};
+    u32x4 ldP[NLDG > 0 ? NLDG : 1];
     size_t eP = 0;
+    char* stage = smem + 2 * HALO_BYTES + wave * (NLDG * 1024);      // wave-uniform: DMA destination base
     f32x4 v0, v1;          // the row that is passing through the epilogue slices
 
     // Slice s (0..17) of the previous half's epilogue: row s/9; step 0 swaps lanes and adds bias and
@@ -610,7 +614,10 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             }
         } else {
             const size_t eo = eP + j * erow;
-            if (TV) { v0 += tP0; v1 += tP1; }
+            if (TV) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v0[q] += u2f(ldP[0][q]); v1[q] += u2f(ldP[1][q]); }
+            }
             if (DDIM) {
                 f32x4 z0, z1;
 #pragma unroll
@@ -641,10 +648,16 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     int img = 0;
     size_t e0 = 0;
 
-    auto tile_top = [&]() {
-        // this tile's halo has landed (issued during the previous tile) and every wave is done
-        // reading the other halo buffer, which the next tile's pieces overwrite from here on
-        wait_vmcnt<0>();
+    // Order of a wave's vector-memory operations in one half (compiler barriers keep it): 3 halo
+    // pieces, NLDG pieces of this half's epilogue inputs, then the 2 x NST stores of the previous half's
+    // epilogue rows.  vmcnt retires in issue order, so "at most 2*NST outstanding" at the start of the
+    // next half means the halo pieces and the staged inputs have landed while the stores may still be
+    // in flight.  There are no plain global loads in the loop: the compiler would drain every LDS-DMA
+    // (vmcnt 0) at the first use of one.
+    auto tile_top = [&](auto first_tag) {
+        if (decltype(first_tag)::value) wait_vmcnt<0>();
+        else wait_vmcnt<2 * NST>();
+        // every wave is done reading the other halo buffer, which the next tile's pieces overwrite
         __builtin_amdgcn_s_barrier();
         halo_origin(tile + (int)gridDim.x);
         img = tile / tiles_per_img;
@@ -652,18 +665,29 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
         e0 = (((size_t)img * a.Hout + y0 + wm * 2 * HR) * a.Wout + x0 + l15) * 64 + co;
     };
+    auto read_staged = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLDG; ++i) ldP[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+    };
 
-    auto do_half = [&](auto half_tag, auto epi_tag) {
+    // half_tag: second half of the tile; epi_tag: a previous half exists (its epilogue runs here);
+    // wait_tag: 0 = the tile top already waited, 1 = wait leaving the previous half's stores in flight,
+    // 2 = wait for everything (the previous half issued no stores)
+    auto do_half = [&](auto half_tag, auto epi_tag, auto wait_tag) {
         constexpr int HALF = decltype(half_tag)::value ? 1 : 0;
         constexpr bool EPI = decltype(epi_tag)::value;
+        constexpr int WAIT = decltype(wait_tag)::value;
+        if (EPI && NLDG > 0) {
+            if (WAIT == 1) wait_vmcnt<2 * NST>();
+            if (WAIT == 2) wait_vmcnt<0>();
+            read_staged();
+        }
         const size_t eC = e0 + HALF * HR * erow;
         f32x4 acc[NF][HR];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < HR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 ldC[NLD];
-        f32x4 tC0 = {0.f, 0.f, 0.f, 0.f}, tC1 = {0.f, 0.f, 0.f, 0.f};
         const char* hp0 = smem + buf * HALO_BYTES + hlane + HALF * HR * (HW * 32);
         // X fragments: a register ring XD half steps deep (LDS latency is longer than the 4 MFMAs of one)
         auto xoff = [&](int k) {
@@ -684,14 +708,14 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             }
             // memory work, one operation per half step
             if (ks < 3) halo_piece(HALF * 3 + ks, buf ^ 1);
-            if (RES && ks >= 4 && ks < 4 + HR)
-                ldC[ks - 4] = *(const u32x4*)(a.res + (eC + (ks - 4) * erow) * 2);
-            if (DDIM && ks >= 4 && ks < 4 + 2 * HR)
-                ldC[ks - 4] = *(const u32x4*)(a.sched_z + eC + ((ks - 4) >> 1) * erow + ((ks - 4) & 1) * 4);
-            if (TV && ks == 4) {
-                const float* tv = a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co;
-                tC0 = *(const f32x4*)tv;
-                tC1 = *(const f32x4*)(tv + 4);
+            if (ks == 3 || ks == 3 + NLDG) asm volatile("" ::: "memory");
+            if (ks >= 3 && ks < 3 + NLDG) {
+                const int i = ks - 3;
+                const char* src;
+                if (RES) src = a.res + (eC + i * erow) * 2;
+                else if (DDIM) src = (const char*)(a.sched_z + eC + (i >> 1) * erow + (i & 1) * 4);
+                else src = (const char*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co + i * 4);
+                glds16(src, stage + i * 1024);
             }
             if (EPI) epi_slice(ks);
 #pragma unroll
@@ -713,25 +737,25 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < HR; ++r) accP[nf][r] = acc[nf][r];
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) ldP[i] = ldC[i];
-        tP0 = tC0;
-        tP1 = tC1;
         eP = eC;
     };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
 
-    tile_top();
-    do_half(BoolC<false>{}, BoolC<false>{});
-    do_half(BoolC<true>{}, BoolC<true>{});
+    tile_top(BoolC<true>{});
+    do_half(BoolC<false>{}, BoolC<false>{}, W0{});
+    do_half(BoolC<true>{}, BoolC<true>{}, W2{});
     tile += gridDim.x;
     buf ^= 1;
     for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
-        tile_top();
-        do_half(BoolC<false>{}, BoolC<true>{});
-        do_half(BoolC<true>{}, BoolC<true>{});
+        tile_top(BoolC<false>{});
+        do_half(BoolC<false>{}, BoolC<true>{}, W0{});
+        do_half(BoolC<true>{}, BoolC<true>{}, W1{});
     }
     // the last half's epilogue
     wait_vmcnt<0>();
+    read_staged();
 #pragma unroll
     for (int s = 0; s < KS; ++s) epi_slice(s);
 
@@ -809,7 +833,7 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
     a.tiles_y = a.Hg / 8;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     a.nblk_n = 1;
-    const size_t lds = 2 * 6 * 4096;                 // two halo buffers of 10x18 pixels
+    const size_t lds = 2 * 6 * 4096 + 4 * 4 * 1024;  // two halo buffers of 10x18 pixels + staged epilogue inputs
     const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
     hipLaunchKernelGGL(tapconv_ws64_kernel<MODE>, dim3(grid), dim3(256), lds, stream, a);
     LDM_HIP(hipGetLastError());
