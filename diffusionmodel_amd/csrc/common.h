@@ -96,6 +96,12 @@ struct ConvCall {
 };
 bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W);
 
+// Fused up-sampling block (convT 4x4/s2 128 -> 64, concat with a 64-channel skip tensor, 1x1 conv to 64):
+// x [B,Hin,Win,128], skip and out [B,2Hin,2Win,64], bf16 NHWC.  `pc` holds the composed weights.
+bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, int Win);
+int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* out, int B, int Hin, int Win,
+                  hipStream_t stream);
+
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
 

@@ -222,6 +222,8 @@ struct ldm_module {
     // packed network
     int clp = 0;   // latent channels padded to the kernel's channel chunk
     PackedConv down1, down2, down3, up1, up_conv1, up2, up_conv2, out_conv;
+    PackedConv up2_fused;          // up2 composed with up_conv2 (bf16, 128 -> 64 only), see pack_up_fused
+    bool have_up2_fused = false;
     ResBlockP rb[7];
     AttnP mid_atten, up_atten;
     float *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twt = nullptr, *tbt = nullptr;
@@ -316,6 +318,49 @@ static int pack_conv1x1_cat(ldm_module* m, const std::string& name, int cin0, in
     sp.src = {cin0, cin1};
     sp.w = [&](int, int, int co, int ci) { return (*w)[(size_t)co * cin + ci]; };
     sp.bias = [&](int co) { return (*b)[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+// up (convT 4x4/s2, cin -> cmid) followed by the 1x1 conv over cat[up, skip] (cmid + cskip -> cout), as one
+// transposed conv over the sources {x, skip}: the 1x1 conv is linear, so
+//   out = (W1a . WT) (*) x + W1b . skip + (b1 + W1a . bT)
+// with W1 = [W1a | W1b] split at cmid.  Composed in double precision.  The skip source is sampled at
+// the output pixel itself: only tap 0 of its chunks carries weights.
+static int pack_up_fused(ldm_module* m, const std::string& up, const std::string& conv, int cin, int cmid, int cskip,
+                         int cout, PackedConv* pc) {
+    const std::vector<float>*wt, *bt, *w1, *b1;
+    LDM_TRY(get_param(m, pjoin(up, "weight"), (size_t)cin * cmid * 16, &wt));
+    LDM_TRY(get_param(m, pjoin(up, "bias"), cmid, &bt));
+    LDM_TRY(get_param(m, pjoin(conv, "weight"), (size_t)cout * (cmid + cskip), &w1));
+    LDM_TRY(get_param(m, pjoin(conv, "bias"), cout, &b1));
+    const int c1 = cmid + cskip;
+    std::vector<float> wc((size_t)cin * cout * 16);     // [ci][co][ky][kx]
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int k = 0; k < 16; ++k) {
+                double acc = 0.0;
+                for (int mm = 0; mm < cmid; ++mm)
+                    acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*wt)[((size_t)ci * cmid + mm) * 16 + k];
+                wc[((size_t)ci * cout + co) * 16 + k] = (float)acc;
+            }
+    std::vector<float> bc(cout);
+    for (int co = 0; co < cout; ++co) {
+        double acc = (*b1)[co];
+        for (int mm = 0; mm < cmid; ++mm) acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*bt)[mm];
+        bc[co] = (float)acc;
+    }
+    PackSpec sp;
+    sp.kind = CONVT4x4_S2;
+    sp.dtype = m->dtype;
+    sp.cout = cout;
+    sp.src = {cin, cskip};
+    sp.w = [&](int ph, int tap, int co, int ci) {
+        if (ci >= cin) return tap == 0 ? (*w1)[(size_t)co * c1 + cmid + (ci - cin)] : 0.f;
+        const int py = ph >> 1, px = ph & 1, ta = tap >> 1, tb = tap & 1;
+        const int ky = 3 - py - 2 * ta, kx = 3 - px - 2 * tb;
+        return wc[((size_t)ci * cout + co) * 16 + ky * 4 + kx];
+    };
+    sp.bias = [&](int co) { return bc[co]; };
     return pack_conv(sp, m->pool, pc, nullptr);
 }
 
@@ -430,6 +475,10 @@ static int finalize_module(ldm_module* m) {
         if (m->scaled) LDM_TRY(pack_attention(m, "up_atten", c2, &m->up_atten));
         LDM_TRY(pack_convT(m, "up2", c2, c1, &m->up2));
         LDM_TRY(pack_conv1x1_cat(m, "up_conv2", c1, c1, c1, &m->up_conv2));
+        if (m->dtype == LDM_BF16 && c2 == 128 && c1 == 64) {
+            LDM_TRY(pack_up_fused(m, "up2", "up_conv2", c2, c1, c1, c1, &m->up2_fused));
+            m->have_up2_fused = true;
+        }
         LDM_TRY(pack_conv3x3(m, "out_conv", "", c1, cl, 1, &m->out_conv));
         LDM_REQUIRE(m->out_conv.cout == m->clp, "internal: padded output and padded latent widths differ");
     }
@@ -544,8 +593,12 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
         LDM_TRY(run_attention(m->up_atten, m->dtype, ub.s2, ub.qkv2, ub.att2, ub.b2, B, H2, W2, st));
         u1 = ub.b2;
     }
-    LDM_TRY(run_conv(m->up2, u1, c2, nullptr, 0, ub.a1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
-    LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (m->have_up2_fused && upfuse_shape_ok(m->dtype, c2, c1, c1, B, H2, W2)) {
+        LDM_TRY(launch_upfuse(m->up2_fused, u1, ub.s1, ub.b1, B, H2, W2, st));      // up2 + cat + up_conv2 -> b1
+    } else {
+        LDM_TRY(run_conv(m->up2, u1, c2, nullptr, 0, ub.a1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+        LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    }
     LDM_TRY(run_resblock(m->rb[6], ub.b1, ub.a1, ub.s1, B, H, W, tv, st));                 // up_res2 -> s1
     if (ddim) {
         ConvCall cc;

@@ -89,7 +89,7 @@ struct TapConvArgs {
     int Hout, Wout, cout;
     int osc;                     // output scale: 2 for convT phases, else 1
     int ntaps;
-    int tiles_x, tiles_y, ntiles, nblk_n;
+    int tiles_x, tiles_y, ntiles, nblk_n, nphase;
     int act, out_f32;
     int t_img_stride, t_step_stride;
     long w_phase_stride;         // bytes
@@ -175,14 +175,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const int wm = wave / WN, wn = wave % WN;
     const int g = lane >> 4, l15 = lane & 15;
 
-    // XCD-aware block -> (tile, channel block): blocks b and b+8 share an XCD (and its L2), so the
-    // channel blocks of one tile, which read the same input window, get ids 8 apart.
+    // XCD-aware block -> (tile, channel block, phase): blocks b and b+8 share an XCD (and its L2), so
+    // the channel blocks and the convT phases of one tile, which all read the same input window, get
+    // ids 8 apart: they run close together in time on one XCD and the window comes from HBM once.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
-    const int tile = (j / a.nblk_n) * 8 + xcd;
-    const int nb = j % a.nblk_n;
+    const int nsub = a.nblk_n * a.nphase;
+    const int tile = (j / nsub) * 8 + xcd;
+    const int sub = j % nsub;
+    const int nb = sub % a.nblk_n;
+    const int phase = sub / a.nblk_n;
     if (tile >= a.ntiles) return;
-    const int phase = blockIdx.z;
     const int img = tile / (a.tiles_x * a.tiles_y);
     const int trem = tile - img * (a.tiles_x * a.tiles_y);
     const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * TW;
@@ -775,6 +778,214 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused up-sampling block of the 64-channel level (bf16): convT 4x4 / stride 2 (128 -> 64), channel
+// concatenation with the skip tensor and the 1x1 conv over the concatenation (src/main.rs:476-483),
+// as ONE weight-stationary kernel.  The 1x1 conv is linear, so its up-sampled half is composed with
+// the transposed conv when the weights are packed:
+//   out = (W1a . WT) (*) x  +  W1b . skip  +  (b1 + W1a . bT)
+// Per sub-pixel phase that is 4 taps x 128 input channels plus one "tap" of 64 skip channels: 18 half
+// steps of 32 channels, the same register budget as the 3x3 kernel above (144 weight registers).
+// A workgroup has 8 waves: wave = (phase, half of the 64 output channels); all waves share ONE input
+// window (the four phases read the same 6x18 pixels, so it crosses L2->LDS once instead of four
+// times) and the 8x32 output-resolution tile of the skip tensor, stored per phase.  Tiles of 4x16 input
+// pixels (8x32 output pixels), double-buffered; rows are processed in two halves with the previous
+// half's epilogue, the stores and the next tile's DMA pieces spread over the MFMAs as above.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void upfuse_ws_kernel(const TapConvArgs a) {
+    constexpr int TH = 4, HW = 18, HP = (TH + 2) * HW, NG = (HP + 31) / 32;    // 108 halo pixels, 4 groups
+    constexpr int XPLANE = NG * 1024, XCHUNK = 4 * XPLANE;                      // 16 KiB per input chunk
+    constexpr int SPLANE = 2 * 1024, SPHASE = 4 * SPLANE;                       // skip: 64 pixels per phase, 8 KiB
+    constexpr int TILE_BYTES = 2 * XCHUNK + 4 * SPHASE;                         // 64 KiB
+    constexpr int NF = 2, KS = 18, HR = 2, XD = 3, NPW = 8;                     // NPW DMA pieces per wave and tile
+    static_assert(NG == 4, "piece numbering");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int phase = wave >> 1, wn = wave & 1;
+    const int py = phase >> 1, px = phase & 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const char* zero = (const char*)g_zero16;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
+
+    // weights of this wave's phase and channel half: slabs 0..7 = (chunk, tap), slab 8 = skip
+    u32x4 wreg[KS][NF];
+    const char* wph = a.w + (size_t)phase * a.w_phase_stride;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            wreg[ks][nf] = *(const u32x4*)(wph + (ks >> 1) * 8192 + ((ks & 1) * 2 + (g >> 1)) * 2048 +
+                                           ((wn * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
+
+    // DMA pieces: waves 0..3 stage the input window (piece e = wave*8 + i: chunk e>>4, group (e>>2)&3,
+    // plane e&3), waves 4..7 the skip tile (e -= 32: phase e>>3, group (e>>2)&1, plane e&3).  Per
+    // piece a lane keeps its pixel's window coordinates (input) or its offset inside the tile (skip).
+    const bool skip_wave = wave >= 4;
+    int pcoord[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        if (!skip_wave) {
+            const int e = wave * NPW + i;
+            const int hp = ((e >> 2) & 3) * 32 + (lane >> 1);
+            const int hy = hp / HW, hx = hp - hy * HW;
+            pcoord[i] = hp < HP ? (hy << 8 | hx) : -1;
+        } else {
+            const int e = (wave - 4) * NPW + i;
+            const int sp = ((e >> 2) & 1) * 32 + (lane >> 1);
+            const int ph = e >> 3;
+            // output pixel (2y + py', 2x + px') relative to the tile's output origin
+            pcoord[i] = ((2 * (sp >> 4) + (ph >> 1)) * a.Wout + 2 * (sp & 15) + (ph & 1)) * 128;
+        }
+    }
+    const char* pbase;
+    int piy0, pix0;
+    bool plive;
+    auto piece_origin = [&](int t) {
+        plive = t < a.ntiles;
+        const int tt = plive ? t : 0;
+        const int img = tt / tiles_per_img;
+        const int trem = tt - img * tiles_per_img;
+        const int ty = trem / a.tiles_x, tx = trem % a.tiles_x;
+        piy0 = ty * TH - 1;
+        pix0 = tx * 16 - 1;
+        if (!skip_wave) pbase = a.in0 + (size_t)img * a.Hin * a.Win * 256 + (lane & 1) * 16;
+        else pbase = a.in1 + (((size_t)img * a.Hout + ty * 2 * TH) * a.Wout + tx * 32) * 128 + (lane & 1) * 16;
+    };
+    auto issue_piece = [&](int i, int buf) {
+        const int e = (wave & 3) * NPW + i;
+        const char* src;
+        unsigned dst;
+        if (!skip_wave) {
+            const int iy = piy0 + (pcoord[i] >> 8), ix = pix0 + (pcoord[i] & 255);
+            const bool ok = plive && pcoord[i] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            src = ok ? pbase + (size_t)(iy * a.Win + ix) * 256 + (e >> 4) * 128 + (e & 3) * 32 : zero;
+            dst = (e >> 4) * XCHUNK + (e & 3) * XPLANE + ((e >> 2) & 3) * 1024;
+        } else {
+            src = plive ? pbase + pcoord[i] + (e & 3) * 32 : zero;
+            dst = 2 * XCHUNK + (e >> 3) * SPHASE + (e & 3) * SPLANE + ((e >> 2) & 1) * 1024;
+        }
+        glds16(src, smem + buf * TILE_BYTES + dst);
+    };
+    piece_origin(tile);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) issue_piece(i, 0);
+
+    // per-lane read bases: input window at the phase's origin, skip tile of the phase
+    const unsigned xlane = (g >> 1) * XPLANE + ((py * HW + px) + l15) * 32 + (g & 1) * 16;
+    const unsigned slane = 2 * XCHUNK + phase * SPHASE + (g >> 1) * SPLANE + l15 * 32 + (g & 1) * 16;
+    // byte offset of (half step ks, row r) inside a tile buffer
+    auto xoff = [&](int ks, int r) -> unsigned {
+        const int sl = ks >> 1, kk = ks & 1;
+        if (sl < 8) {
+            const int c = sl >> 2, ta = (sl >> 1) & 1, tb = sl & 1;
+            return xlane + c * XCHUNK + kk * 2 * XPLANE + ((r + ta) * HW + tb) * 32;
+        }
+        return slane + kk * 2 * SPLANE + r * 16 * 32;
+    };
+
+    const int co = wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
+    const size_t erow = (size_t)2 * a.Wout * 64;       // one phase row = two output rows
+    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+
+    f32x4 accP[NF][HR];
+    size_t eP = 0;
+    auto epilogue_row = [&](int j) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[1][j][q]), false, false);
+            v0[q] = u2f(sw[0]);
+            v1[q] = u2f(sw[1]);
+        }
+        v0 += b0;
+        v1 += b1;
+        u32x4 o;
+        o[0] = pack2(v0[0], v0[1]);
+        o[1] = pack2(v0[2], v0[3]);
+        o[2] = pack2(v1[0], v1[1]);
+        o[3] = pack2(v1[2], v1[3]);
+        *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
+    };
+
+    int buf = 0;
+    size_t e0 = 0;
+    // Order of a wave's vector-memory operations in one half: 4 DMA pieces, then the 2 stores of the
+    // previous half's rows; "at most 2 outstanding" at a tile top = all pieces have landed.
+    auto tile_top = [&](auto first_tag) {
+        if (decltype(first_tag)::value) wait_vmcnt<0>();
+        else wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        piece_origin(tile + (int)gridDim.x);
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int oy0 = (trem / a.tiles_x) * 2 * TH + py, ox0 = (trem % a.tiles_x) * 32 + px;
+        e0 = (((size_t)img * a.Hout + oy0) * a.Wout + ox0 + 2 * l15) * 64 + co;
+    };
+    auto do_half = [&](auto half_tag, auto epi_tag) {
+        constexpr int HALF = decltype(half_tag)::value ? 1 : 0;
+        constexpr bool EPI = decltype(epi_tag)::value;
+        const size_t eC = e0 + HALF * HR * erow;
+        f32x4 acc[NF][HR];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* tb = smem + buf * TILE_BYTES;
+        u32x4 xf[XD][HR];
+#pragma unroll
+        for (int k = 0; k < XD - 1; ++k)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) xf[k][r] = *(const u32x4*)(tb + xoff(k, HALF * HR + r));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + XD - 1 < KS) {
+#pragma unroll
+                for (int r = 0; r < HR; ++r)
+                    xf[(ks + XD - 1) % XD][r] = *(const u32x4*)(tb + xoff(ks + XD - 1, HALF * HR + r));
+            }
+            if (ks < NPW / 2) issue_piece(HALF * (NPW / 2) + ks, buf ^ 1);
+            if (ks == NPW / 2) asm volatile("" ::: "memory");
+            if (EPI && ks == 8) epilogue_row(0);
+            if (EPI && ks == 17) epilogue_row(1);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < HR; ++r)
+                    acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[ks % XD][r]),
+                        acc[nf][r], 0, 0, 0);
+            if (ks + XD - 1 < KS) {
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) accP[nf][r] = acc[nf][r];
+        eP = eC;
+    };
+
+    tile_top(BoolC<true>{});
+    do_half(BoolC<false>{}, BoolC<false>{});
+    do_half(BoolC<true>{}, BoolC<true>{});
+    tile += gridDim.x;
+    buf ^= 1;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        tile_top(BoolC<false>{});
+        do_half(BoolC<false>{}, BoolC<true>{});
+        do_half(BoolC<true>{}, BoolC<true>{});
+    }
+    epilogue_row(0);
+    epilogue_row(1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -808,7 +1019,8 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8 * a.nblk_n), 1, (unsigned)nphase);
+    a.nphase = nphase;
+    dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8 * a.nblk_n * nphase), 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
@@ -911,6 +1123,41 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 4, 2>(a, nph, stream);
     if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 4, 2>(a, nph, stream);
     return launch_cfg<T, 4, 64, 2, 2, 1, 3, 4, 2>(a, nph, stream);
+}
+
+bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, int Win) {
+    return dtype == LDM_BF16 && cin == 128 && cskip == 64 && cout == 64 && Hin % 4 == 0 && Win % 16 == 0 &&
+           (long)B * (Hin / 4) * (Win / 16) >= 256 && (size_t)Hin * Win * 256 * 4 < (1ull << 31) && !TAPCONV_NO_WS64;
+}
+
+// pc: packed by pack_conv as CONVT4x4_S2 over the sources {128 composed input channels, 64 skip channels}
+// (the skip chunk's tap 0 holds the 1x1 weights, its other taps are unused)
+int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* out, int B, int Hin, int Win,
+                  hipStream_t stream) {
+    LDM_REQUIRE(x && skip && out && pc.w && pc.bias, "null tensor");
+    LDM_REQUIRE(pc.kind == CONVT4x4_S2 && pc.cin == 192 && upfuse_shape_ok(pc.dtype, 128, 64, pc.cout, B, Hin, Win),
+                "shape not served by the fused up-sampling kernel");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        LDM_HIP(hipGetDevice(&dev));
+        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    TapConvArgs a{};
+    a.in0 = (const char*)x; a.in1 = (const char*)skip; a.w = (const char*)pc.w; a.bias = pc.bias; a.out = (char*)out;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = 2 * Hin; a.Wout = 2 * Win; a.cout = 64;
+    a.tiles_x = Win / 16; a.tiles_y = Hin / 4; a.ntiles = a.tiles_x * a.tiles_y * B;
+    a.w_phase_stride = (long)3 * 4 * 64 * 128;       // three chunks x four taps of 8-KiB slabs per phase
+    const size_t lds = 2 * 64 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDM_HIP(hipFuncSetAttribute((const void*)upfuse_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL(upfuse_ws_kernel, dim3(grid), dim3(512), lds, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
 }
 
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream) {

@@ -136,13 +136,16 @@ def test_attention_running_max_jump(A, O, dtype, spike_at):
 
 # ---- full UNet forward --------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("Cl,B,S", [(64, 4, 4), (64, 2, 16), (8, 2, 8), (64, 1, 64)])
+@pytest.mark.parametrize("Cl,B,S", [(64, 4, 4), (64, 2, 16), (8, 2, 8), (64, 1, 64), (64, 16, 64)])
 def test_unet_forward(A, O, dtype, Cl, B, S):
+    # (64, 16, 64) is large enough for the weight-stationary 64-channel kernels and the fused
+    # up-sampling block (bf16); the smaller cases run the generic tap-conv kernel everywhere
+    te_all = [7, 31, 0, 49, 3, 12, 25, 44, 1, 2, 8, 16, 33, 40, 48, 5]
     cfg = A.LDMConfig(in_channels=Cl)
     w = A.make_synthetic_weights(cfg, 0)
     torch.manual_seed(3)
     x = torch.randn(B, Cl, S, S)
-    te = O.sin_time_addition(torch.tensor([7, 31, 0, 49][:B]), 256)
+    te = O.sin_time_addition(torch.tensor(te_all[:B]), 256)
     ref = O.unet_forward(w, x, te)
     _say(f"unet {dtype} Cl={Cl} B={B} S={S}")
     net = A.UNet(Cl, 256, dtype=dtype, weights=w)
