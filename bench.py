@@ -77,6 +77,19 @@ def time_dominant_kernel(A, dtype, B, S, C, iters=30):
     return ms, flop
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE, separate passes), or None when no record matches this kernel and shape."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = rec.get(kernel_name)
+    return float(ent["hbm_bytes_per_launch"]) if ent else None
+
+
 def cpu_baseline(steps_sample=5):
     """CPU restatement (oracle) on the host: config 1 = 50-step DDPM, B = 4, 64x64 latents, f32."""
     from oracle import ldm_oracle as O
@@ -182,9 +195,16 @@ def main():
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
 
     if rank == 0:
-        c_dom = cfg.channels[0]
-        kms, kflop = time_dominant_kernel(A, args.dtype, B, S, c_dom)
+        # dominant kernel by share of the step (profiles/): the 3x3 tap convolution of the innermost
+        # level (six launches per UNet step: down_res3, mid_res1, mid_res2 = 2 convs each)
+        c_dom, s_dom = cfg.channels[2], S // 4
+        kms, kflop = time_dominant_kernel(A, args.dtype, B, s_dom, c_dom)
         achieved = kflop / (kms * 1e-3) / 1e12
+        kname = f"tapconv 3x3 {c_dom}->{c_dom} on [{B},{s_dom},{s_dom},{c_dom}] {args.dtype}"
+        levels = {}
+        for lv, (cc, ss) in enumerate(((cfg.channels[0], S), (cfg.channels[1], S // 2))):
+            ms_l, fl_l = time_dominant_kernel(A, args.dtype, B, ss, cc)
+            levels[f"tapconv 3x3 {cc}->{cc} on [{B},{ss},{ss},{cc}]"] = {"avg_ms": ms_l, "tflops": fl_l / (ms_l * 1e-3) / 1e12}
         res = {
             "metric": "images/sec (50-step DDIM)" if args.sampler == "ddim" else f"images/sec ({n_unet_steps}-step DDPM)",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,9 +219,8 @@ def main():
             "unet_tflops": flop_step * unet_steps_per_s / 1e12,
             "unet_frac_of_mfma_peak": flop_step * unet_steps_per_s / 1e12 / peak,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "kernel": f"tapconv 3x3 {c_dom}->{c_dom} on [{B},{S},{S},{c_dom}] {args.dtype}",
-                         "avg_ms": kms, "flop_per_launch": kflop},
+                         "frac": achieved / peak, "traffic": pmc_traffic(kname),
+                         "kernel": kname, "avg_ms": kms, "flop_per_launch": kflop, "other_levels": levels},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -49,7 +49,7 @@
 #define TAPCONV_NO_WS64 0
 #endif
 #ifndef TAPCONV_WS_XD
-#define TAPCONV_WS_XD 3
+#define TAPCONV_WS_XD 4
 #endif
 #ifndef TAPCONV_1X1_RING
 #define TAPCONV_1X1_RING 3
@@ -692,48 +692,49 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
 #pragma unroll
             for (int r = 0; r < HR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* hp0 = smem + buf * HALO_BYTES + hlane + HALF * HR * (HW * 32);
-        // X fragments: a register ring XD half steps deep (LDS latency is longer than the 4 MFMAs of one)
-        auto xoff = [&](int k) {
-            const int t = k >> 1, kk = k & 1;
-            return kk * 2 * HPLANE + ((t / 3) * HW + (t % 3)) * 32;
-        };
-        u32x4 xf[XD][HR];
+        // The X fragment of (window row h, column shift dx, channel half kk) serves every (output row
+        // r, tap row dy) with r + dy = h, so it is read from LDS once: 24 fragments per half instead of
+        // 36 (an LDS read per two MFMAs would saturate the LDS at two waves per SIMD).  Fragments go
+        // through a register ring XD deep; fragment f = (h, dx, kk) with kk fastest.
+        constexpr int NFR = (HR + 2) * 6;
+        auto foff = [&](int f) { return (f & 1) * 2 * HPLANE + ((f / 6) * HW + ((f % 6) >> 1)) * 32; };
+        u32x4 xf[XD];
 #pragma unroll
-        for (int k = 0; k < XD - 1; ++k)
+        for (int f = 0; f < XD - 1; ++f) xf[f] = *(const u32x4*)(hp0 + foff(f));
+        int slice = 0;
 #pragma unroll
-            for (int r = 0; r < HR; ++r) xf[k][r] = *(const u32x4*)(hp0 + xoff(k) + r * (HW * 32));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + XD - 1 < KS) {
-#pragma unroll
-                for (int r = 0; r < HR; ++r)
-                    xf[(ks + XD - 1) % XD][r] = *(const u32x4*)(hp0 + xoff(ks + XD - 1) + r * (HW * 32));
-            }
-            // memory work, one operation per half step
-            if (ks < 3) halo_piece(HALF * 3 + ks, buf ^ 1);
-            if (ks == 3 || ks == 3 + NLDG) asm volatile("" ::: "memory");
-            if (ks >= 3 && ks < 3 + NLDG) {
-                const int i = ks - 3;
+        for (int f = 0; f < NFR; ++f) {
+            if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *(const u32x4*)(hp0 + foff(f + XD - 1));
+            // memory work, one operation per fragment step
+            if (f < 3) halo_piece(HALF * 3 + f, buf ^ 1);
+            if (f == 3 || f == 3 + NLDG) asm volatile("" ::: "memory");
+            if (f >= 3 && f < 3 + NLDG) {
+                const int i = f - 3;
                 const char* src;
                 if (RES) src = a.res + (eC + i * erow) * 2;
                 else if (DDIM) src = (const char*)(a.sched_z + eC + (i >> 1) * erow + (i & 1) * 4);
                 else src = (const char*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co + i * 4);
                 glds16(src, stage + i * 1024);
             }
-            if (EPI) epi_slice(ks);
+            // 18 epilogue slices over the 24 fragment steps (the stores fall on steps 10 and 22)
+            if (EPI && f % 4 != 3) epi_slice(slice);
+            if (f % 4 != 3) ++slice;
+            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = h - dy;
+                if (r < 0 || r >= HR) continue;
 #pragma unroll
-                for (int r = 0; r < HR; ++r)
+                for (int nf = 0; nf < NF; ++nf)
                     acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[ks % XD][r]),
+                        __builtin_bit_cast(bf16x8, wreg[(dy * 3 + dx) * 2 + kk][nf]), __builtin_bit_cast(bf16x8, xf[f % XD]),
                         acc[nf][r], 0, 0, 0);
-            if (ks + XD - 1 < KS) {
-#pragma unroll
-                for (int r = 0; r < HR; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+            }
+            static_assert(HR == 2, "MFMAs per fragment step: one (r, dy) pair for h = 0 and 3, two for h = 1 and 2");
+            if (f + XD - 1 < NFR) {
+                if (h == 0 || h == HR + 1) __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
 #pragma unroll
