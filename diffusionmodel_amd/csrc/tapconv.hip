@@ -52,7 +52,7 @@
 #define TAPCONV_WS_XD 4
 #endif
 #ifndef TAPCONV_1X1_RING
-#define TAPCONV_1X1_RING 3
+#define TAPCONV_1X1_RING 2
 #endif
 #ifndef TAPCONV_RING_L1
 #define TAPCONV_RING_L1 3
@@ -323,11 +323,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         }
     };
 
-    // prologue: halo 0, then slabs 0 .. D-1; wait for halo 0 and slab 0 only
+    // Two schedules.  RING <= 3: the barrier at the end of step s publishes slab s+1, so the first reads
+    // of step s+1 can only be issued after it and their LDS latency is exposed once per step.
+    // EARLY (RING >= 4, more than one tap per chunk): the barrier publishes slab s+2 instead; the reads
+    // of step s+1's first half are then issued BEFORE the barrier, behind the MFMAs of step s, and the
+    // register double-buffering of fragments runs straight across the barrier.
+    constexpr bool EARLY = RING >= 4 && NTAPS > 1;
+    constexpr int PUB = EARLY ? 2 : 1;           // the barrier of step s publishes slab s + PUB
+
+    // prologue: halo 0, then slabs 0 .. D-1; wait for halo 0 and the slabs below PUB
     issue_halo(0);
     const int npro = nsteps < D ? nsteps : D;
     for (int d = 0; d < npro; ++d) issue_w(d, d);
-    wait_leaving(npro - 1, false);
+    {
+        const int need = PUB - 1 < nsteps - 1 ? PUB - 1 : nsteps - 1;
+        wait_leaving(npro - 1 - need, false);
+    }
     __builtin_amdgcn_s_barrier();
 
     // Software pipeline over half steps: while the MFMAs of one half run, the LDS reads of the next
@@ -347,28 +358,36 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             if (halo_now) issue_halo(c + 1);      // older than slab s+D: a later counted wait covers it
             if (s + D < nsteps && !(TAPCONV_ABLATE & 2)) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
             const unsigned wb = wbuf0 + slot * WSLAB;
+            const int slot_next = slot + 1 == RING ? 0 : slot + 1;
+            // first half of the next step (after the very last step this reads LDS that nobody uses:
+            // harmless, and reads and MFMAs stay in one basic block for the interleave)
+            const bool wrap = t == NTAPS - 1;
+            const unsigned hbn = wrap ? hbuf0 + (more_chunks ? ((c + 1) & 1) : 0) * HALO_BYTES : hb;
             if constexpr (!(TAPCONV_ABLATE & 4)) {
                 load_frags(1, hb, wb, t, wfB, xfB);
                 mfma_batch(wfA, xfA);
                 interleave_reads_with_mfma();
+                if constexpr (EARLY) {
+                    load_frags(0, hbn, wbuf0 + slot_next * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
+                    mfma_batch(wfB, xfB);
+                    interleave_reads_with_mfma();
+                }
             }
-            // What must have landed before the next step: slab s+1 and, if it opens a chunk, that
-            // chunk's halo.  Younger pieces may stay in flight: the slabs s+2 .. s+D that exist, and
-            // the next chunk's halo while it is younger than slab s+1 (it was issued at tap 0, slab
-            // s+1 at step s+1-D) and the next step still belongs to this chunk.  lgkmcnt(0): this
-            // step's LDS reads are complete before any wave may overwrite what they read.
+            // What must have landed before the barrier: slab s+PUB and, if step s+PUB opens a chunk,
+            // that chunk's halo.  Younger pieces may stay in flight: the later slabs that exist, and the
+            // next chunk's halo while it is younger than slab s+PUB (the halo is issued at tap 0, slab
+            // s+PUB at step s+PUB-D) and step s+PUB still belongs to this chunk.
+            const int need = s + PUB < nsteps - 1 ? s + PUB : nsteps - 1;
             const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
-            const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - (s + 1) > 0 ? last - (s + 1) : 0);
-            const bool h_young = more_chunks && t <= D - 2 && t <= NTAPS - 2 && !(TAPCONV_ABLATE & 16);
+            const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - need > 0 ? last - need : 0);
+            const bool h_young = more_chunks && t <= D - 1 - PUB && t <= NTAPS - 1 - PUB && !(TAPCONV_ABLATE & 16);
             wait_leaving(young, h_young);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // RING <= 3: this step's LDS reads are complete before any wave may overwrite what they
+            // read.  EARLY: a slot is overwritten a whole step after its last read was consumed.
+            if constexpr (!EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (++slot == RING) slot = 0;
-            if constexpr (!(TAPCONV_ABLATE & 4)) {
-                // first half of the next step (after the very last step this reads LDS that nobody
-                // uses: harmless, and reads and MFMAs stay in one basic block for the interleave)
-                const bool wrap = t == NTAPS - 1;
-                const unsigned hbn = wrap ? hbuf0 + (more_chunks ? ((c + 1) & 1) : 0) * HALO_BYTES : hb;
+            slot = slot_next;
+            if constexpr (!(TAPCONV_ABLATE & 4) && !EARLY) {
                 load_frags(0, hbn, wbuf0 + slot * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
                 mfma_batch(wfB, xfB);
                 interleave_reads_with_mfma();
@@ -1108,6 +1127,9 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     if (pc.kind == CONVT4x4_S2 && bn == 64 && th > 8) th = 8;   // two workgroups per CU (LDS) beat the taller tile
     if (pc.kind == CONV3x3_S1) {
         if (bn == 128) {
+            // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
+            // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
+            if (th == 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2>(a, nph, stream);
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
