@@ -206,7 +206,7 @@ def main():
             ms_l, fl_l = time_dominant_kernel(A, args.dtype, B, ss, cc)
             levels[f"tapconv 3x3 {cc}->{cc} on [{B},{ss},{ss},{cc}]"] = {"avg_ms": ms_l, "tflops": fl_l / (ms_l * 1e-3) / 1e12}
         res = {
-            "metric": "images/sec (50-step DDIM)" if args.sampler == "ddim" else f"images/sec ({n_unet_steps}-step DDPM)",
+            "metric": f"images/sec ({n_unet_steps}-step {args.sampler.upper()})",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

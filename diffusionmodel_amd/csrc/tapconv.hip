@@ -51,6 +51,9 @@
 #ifndef TAPCONV_WS_XD
 #define TAPCONV_WS_XD 4
 #endif
+#ifndef TAPCONV_EARLY
+#define TAPCONV_EARLY 0
+#endif
 #ifndef TAPCONV_1X1_RING
 #define TAPCONV_1X1_RING 2
 #endif
@@ -96,7 +99,30 @@ struct TapConvArgs {
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
+#ifdef TAPCONV_STAMP
+    unsigned long long* dbg;     // diagnostic builds: cycle stamps of workgroup 0
+#endif
 };
+
+// Diagnostic cycle stamps (builds with -DTAPCONV_STAMP only).  s_memtime is issued without a wait and
+// collected after the step's own s_waitcnt lgkmcnt(0); the values go to LDS (no vmcnt side effect) and are
+// copied to global memory at the end of the kernel.
+#ifdef TAPCONV_STAMP
+#define STAMP_ISSUE(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define STAMP_STORE(idx, var)                                                                        \
+    do {                                                                                             \
+        unsigned int lo_, hi_;                                                                       \
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo_), "=v"(hi_)                    \
+                     : "s"((unsigned int)(var)), "s"((unsigned int)((var) >> 32)));                  \
+        if (lane == 0 && stamp_on && (idx) < 250) {                                                   \
+            *(unsigned int*)(smem + stamp_base + (idx) * 8) = lo_;                                    \
+            *(unsigned int*)(smem + stamp_base + (idx) * 8 + 4) = hi_;                                \
+        }                                                                                            \
+    } while (0)
+#else
+#define STAMP_ISSUE(var) do { } while (0)
+#define STAMP_STORE(idx, var) do { } while (0)
+#endif
 
 
 // SiLU.  f32 mode divides exactly; bf16 mode multiplies by the hardware reciprocal (1 ulp of f32, far
@@ -150,6 +176,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     constexpr int TW = 16;
     constexpr int HH = (TH - 1) * S + KEXT;
     constexpr int HW = (TW - 1) * S + KEXT;
+    constexpr int HWE = (HW + 1) / 2;            // even columns of a window row (stride-2 layout)
     constexpr int HP = HH * HW;
     constexpr int NG = (HP + 31) / 32;           // groups of 32 halo pixels
     constexpr int HPLANE = NG * 1024;            // one pair plane of the halo
@@ -199,6 +226,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const unsigned hbuf0 = 0;
     const unsigned wbuf0 = nhalo * HALO_BYTES;
     const unsigned dump = wbuf0 + RING * WSLAB;
+#ifdef TAPCONV_STAMP
+    const unsigned stamp_base = dump + 1024 + (wave == 0 ? 0 : 2048);
+    const bool stamp_on = a.dbg && blockIdx.x == 8 && (wave == 0 || wave == NWV - 1);
+    unsigned long long tsA = 0, tsB = 0, tsC = 0;
+    int sidx = 1;
+    if (stamp_on) for (int i = lane; i < 500; i += 64) *(unsigned int*)(smem + stamp_base + i * 4) = 0u;
+    STAMP_ISSUE(tsA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP_STORE(0, tsA);
+#endif
 
     const char* in0_img = a.in0 + (size_t)img * a.Hin * a.Win * a.cin0_bytes;
     const char* in1_img = a.in1 ? a.in1 + (size_t)img * a.Hin * a.Win * a.cin1_bytes : nullptr;
@@ -215,7 +252,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     for (int q = 0; q < NHW; ++q) {
         const int grp = (wave + NWV * q) >> 2;
         const int hp = grp * 32 + (lane >> 1);
-        const int hy = hp / HW, hx = hp - hy * HW;
+        // stride 2: a window row is stored de-interleaved (even columns, then odd columns), so that the 16
+        // pixels of a fragment (every second column) are consecutive slots and its read is conflict free
+        const int hy = hp / HW, hr = hp - hy * HW;
+        const int hx = S == 2 ? (hr < HWE ? 2 * hr : 2 * (hr - HWE) + 1) : hr;
         const int iy = iy0 + hy, ix = ix0 + hx;
         const bool ok = grp < NG && hp < HP && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         hpix[q] = ok ? (iy * a.Win + ix) : -1;
@@ -251,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const unsigned wlane = (g >> 1) * WPLANE + ((wn * NF) * 16 + l15) * 32 + (g & 1) * 16;
     const int py = phase >> 1, px = phase & 1;
     const int origin = NTAPS == 4 ? py * HW + px : 0;   // convT: the phase's window origin
-    const unsigned hlane = (g >> 1) * HPLANE + ((wm * MF * S) * HW + l15 * S + origin) * 32 + (g & 1) * 16;
+    const unsigned hlane = (g >> 1) * HPLANE + ((wm * MF * S) * HW + l15 * (S == 2 ? 1 : S) + origin) * 32 + (g & 1) * 16;
 
     f32x4 acc[NF][MF];
 #pragma unroll
@@ -263,7 +303,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     auto load_frags = [&](int kk, unsigned hb, unsigned wb, int t, u32x4 (&wf)[NF], u32x4 (&xf)[MF]) {
         const char* wp = smem + wb + wlane;
         const char* hp = smem + hb + hlane;
-        const int toff = (tap_dy<NTAPS>(t) * HW + tap_dx<NTAPS>(t)) * 32;
+        const int dx = tap_dx<NTAPS>(t);
+        const int toff = (tap_dy<NTAPS>(t) * HW + (S == 2 ? (dx & 1) * HWE + (dx >> 1) : dx)) * 32;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const u32x4*)(wp + kk * 2 * WPLANE + nf * 512);
 #pragma unroll
@@ -328,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     // EARLY (RING >= 4, more than one tap per chunk): the barrier publishes slab s+2 instead; the reads
     // of step s+1's first half are then issued BEFORE the barrier, behind the MFMAs of step s, and the
     // register double-buffering of fragments runs straight across the barrier.
-    constexpr bool EARLY = RING >= 4 && NTAPS > 1;
+    constexpr bool EARLY = RING >= 4 && NTAPS > 1 && TAPCONV_EARLY;
     constexpr int PUB = EARLY ? 2 : 1;           // the barrier of step s publishes slab s + PUB
 
     // prologue: halo 0, then slabs 0 .. D-1; wait for halo 0 and the slabs below PUB
@@ -354,6 +395,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         for (int t = 0; t < NTAPS; ++t, ++s) {
             // slab s+D goes to the ring slot that step s-1 read; every wave finished those reads
             // before it passed that step's barrier
+            STAMP_ISSUE(tsA);
             const bool halo_now = t == 0 && more_chunks;
             if (halo_now) issue_halo(c + 1);      // older than slab s+D: a later counted wait covers it
             if (s + D < nsteps && !(TAPCONV_ABLATE & 2)) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
@@ -381,10 +423,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
             const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - need > 0 ? last - need : 0);
             const bool h_young = more_chunks && t <= D - 1 - PUB && t <= NTAPS - 1 - PUB && !(TAPCONV_ABLATE & 16);
+#ifdef TAPCONV_STAMP
+            STAMP_ISSUE(tsB);        // (waits for the LDS reads as a side effect)
+#endif
             wait_leaving(young, h_young);
             // RING <= 3: this step's LDS reads are complete before any wave may overwrite what they
             // read.  EARLY: a slot is overwritten a whole step after its last read was consumed.
             if constexpr (!EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TAPCONV_STAMP
+            STAMP_ISSUE(tsC);
+            STAMP_STORE(sidx, tsA); STAMP_STORE(sidx + 1, tsB); STAMP_STORE(sidx + 2, tsC);
+            sidx += 3;
+#endif
             __builtin_amdgcn_s_barrier();
             slot = slot_next;
             if constexpr (!(TAPCONV_ABLATE & 4) && !EARLY) {
@@ -402,6 +452,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     //   v = acc + bias (+ residual) -> activation -> (+ time vector) -> store
     // All operand buffers in LDS are dead here (every wave is past the last barrier; the DMA queue
     // was drained by the last counted wait).
+#ifdef TAPCONV_STAMP
+    // copy the loop's stamps out before the staging area overwrites nothing of them (they sit past the dump)
+    STAMP_ISSUE(tsA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP_STORE(sidx, tsA);
+    ++sidx;
+#endif
     constexpr int BM = TH * 16;
     constexpr int RS = BN * 4 + 16;              // staging row stride (bytes): +16 keeps ds_write_b128 conflict free
     constexpr int NTHR = 64 * NWV;
@@ -482,6 +539,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             if (st) *(u32x4*)(a.out + eo[i] * 2) = o;
         }
     }
+#ifdef TAPCONV_STAMP
+    STAMP_ISSUE(tsA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP_STORE(sidx, tsA);
+    __syncthreads();
+    if (stamp_on)
+        for (int i = lane; i < 250; i += 64)
+            a.dbg[(wave == 0 ? 0 : 256) + i] = *(const unsigned long long*)(smem + stamp_base + i * 8);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1027,6 +1093,11 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     size_t lds = (size_t)(nchunks > 1 ? 2 : 1) * HALO_BYTES + RING * (size_t)BN * 128 + 1024;
     const size_t staging = (size_t)TH * 16 * (BN * 4 + 16);   // epilogue: f32 tile with padded rows
     if (lds < staging) lds = staging;
+#ifdef TAPCONV_STAMP
+    lds += 1024 + 4096;
+    a.dbg = nullptr;
+    if (const char* e = getenv("LDM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
     static_assert((size_t)TH * 16 * (BN * 4 + 16) <= 160 * 1024, "epilogue staging exceeds LDS");
     a.tiles_x = (a.Wg + 15) / 16;
     a.tiles_y = (a.Hg + TH - 1) / TH;
@@ -1129,7 +1200,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if (bn == 128) {
             // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
             // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
-            if (th == 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2>(a, nph, stream);
+            if (th == 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L3>(a, nph, stream);
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
