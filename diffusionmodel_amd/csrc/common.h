@@ -68,6 +68,8 @@ struct PackedConv {
     int cin = 0;            // padded total input channels (multiple of chunk)
     int cout = 0;           // padded output channels (multiple of 64)
     int ntaps = 0, nphase = 1;
+    int ntaps1 = 0;         // taps of the second source's chunks: = ntaps, or 1 for a transposed conv whose second
+                            // source is sampled at the output pixel (fused convT + concat + 1x1)
     void* w = nullptr;      // [phase][chunk][tap][pair plane 0..3][cout][2 pieces of 16 bytes]
     float* bias = nullptr;  // [cout]
     size_t w_bytes = 0;

@@ -129,6 +129,7 @@ struct PackSpec {
     int cout = 0;                 // real output channels
     std::vector<int> src;         // real channels of each source (1 or 2 sources)
     int src0_padto = 0;           // pad source 0 to this many channels (0: to the kernel's channel chunk)
+    int ntaps1 = 0;               // taps of the second source's chunks (0: the same as the first source's)
     std::function<float(int phase, int tap, int co, int ci)> w;   // ci over the concatenated real channels
     std::function<float(int co)> bias;
 };
@@ -156,16 +157,21 @@ static int pack_conv(const PackSpec& sp, DevPool& pool, PackedConv* pc, int* src
     pc->cout = round_up_i(sp.cout, 64);
     pc->nphase = sp.kind == CONVT4x4_S2 ? 4 : 1;
     pc->ntaps = (sp.kind == CONV3x3_S1 || sp.kind == CONV3x3_S2) ? 9 : (sp.kind == CONVT4x4_S2 ? 4 : 1);
-    const size_t nel = (size_t)pc->nphase * nchunks * pc->ntaps * pc->cout * ck;
+    pc->ntaps1 = sp.ntaps1 > 0 ? sp.ntaps1 : pc->ntaps;
+    const int nch_src0 = sp.src.size() == 2 ? ch0[1] : nchunks;
+    const size_t slabs_per_phase = (size_t)nch_src0 * pc->ntaps + (size_t)(nchunks - nch_src0) * pc->ntaps1;
+    const size_t nel = (size_t)pc->nphase * slabs_per_phase * pc->cout * ck;
     std::vector<float> wf(sp.dtype == LDM_F32 ? nel : 0);
     std::vector<bf16_t> wh(sp.dtype == LDM_BF16 ? nel : 0);
     for (int ph = 0; ph < pc->nphase; ++ph)
         for (int c = 0; c < nchunks; ++c) {
             const int s = (sp.src.size() == 2 && c >= ch0[1]) ? 1 : 0;
-            for (int t = 0; t < pc->ntaps; ++t)
+            const int nt = s == 0 ? pc->ntaps : pc->ntaps1;
+            const size_t slab0 = c < nch_src0 ? (size_t)c * pc->ntaps : (size_t)nch_src0 * pc->ntaps + (size_t)(c - nch_src0) * pc->ntaps1;
+            for (int t = 0; t < nt; ++t)
                 for (int co = 0; co < pc->cout; ++co) {
                     // slab = 4 pair planes; plane pp holds the 16-byte pieces 2pp and 2pp+1 of every row
-                    const size_t slab = (((size_t)ph * nchunks + c) * pc->ntaps + t) * pc->cout * ck;
+                    const size_t slab = ((size_t)ph * slabs_per_phase + slab0 + t) * pc->cout * ck;
                     for (int e = 0; e < ck; ++e) {
                         const int cs = (c - ch0[s]) * ck + e;
                         float v = 0.f;
@@ -222,8 +228,8 @@ struct ldm_module {
     // packed network
     int clp = 0;   // latent channels padded to the kernel's channel chunk
     PackedConv down1, down2, down3, up1, up_conv1, up2, up_conv2, out_conv;
-    PackedConv up2_fused;          // up2 composed with up_conv2 (bf16, 128 -> 64 only), see pack_up_fused
-    bool have_up2_fused = false;
+    PackedConv up1_fused, up2_fused;   // up1 / up2 composed with up_conv1 / up_conv2 (bf16), see pack_up_fused
+    bool have_up_fused = false;
     ResBlockP rb[7];
     AttnP mid_atten, up_atten;
     float *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twt = nullptr, *tbt = nullptr;
@@ -325,7 +331,7 @@ static int pack_conv1x1_cat(ldm_module* m, const std::string& name, int cin0, in
 // transposed conv over the sources {x, skip}: the 1x1 conv is linear, so
 //   out = (W1a . WT) (*) x + W1b . skip + (b1 + W1a . bT)
 // with W1 = [W1a | W1b] split at cmid.  Composed in double precision.  The skip source is sampled at
-// the output pixel itself: only tap 0 of its chunks carries weights.
+// the output pixel itself: its chunks have a single tap.
 static int pack_up_fused(ldm_module* m, const std::string& up, const std::string& conv, int cin, int cmid, int cskip,
                          int cout, PackedConv* pc) {
     const std::vector<float>*wt, *bt, *w1, *b1;
@@ -354,6 +360,7 @@ static int pack_up_fused(ldm_module* m, const std::string& up, const std::string
     sp.dtype = m->dtype;
     sp.cout = cout;
     sp.src = {cin, cskip};
+    sp.ntaps1 = 1;
     sp.w = [&](int ph, int tap, int co, int ci) {
         if (ci >= cin) return tap == 0 ? (*w1)[(size_t)co * c1 + cmid + (ci - cin)] : 0.f;
         const int py = ph >> 1, px = ph & 1, ta = tap >> 1, tb = tap & 1;
@@ -475,9 +482,10 @@ static int finalize_module(ldm_module* m) {
         if (m->scaled) LDM_TRY(pack_attention(m, "up_atten", c2, &m->up_atten));
         LDM_TRY(pack_convT(m, "up2", c2, c1, &m->up2));
         LDM_TRY(pack_conv1x1_cat(m, "up_conv2", c1, c1, c1, &m->up_conv2));
-        if (m->dtype == LDM_BF16 && c2 == 128 && c1 == 64) {
+        if (m->dtype == LDM_BF16) {
+            LDM_TRY(pack_up_fused(m, "up1", "up_conv1", c3, c2, c2, c2, &m->up1_fused));
             LDM_TRY(pack_up_fused(m, "up2", "up_conv2", c2, c1, c1, c1, &m->up2_fused));
-            m->have_up2_fused = true;
+            m->have_up_fused = true;
         }
         LDM_TRY(pack_conv3x3(m, "out_conv", "", c1, cl, 1, &m->out_conv));
         LDM_REQUIRE(m->out_conv.cout == m->clp, "internal: padded output and padded latent widths differ");
@@ -585,16 +593,23 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
     LDM_TRY(run_resblock(m->rb[3], ub.c3, ub.b3, ub.a3, B, H3, W3, tv, st));               // mid_res1 -> a3
     LDM_TRY(run_attention(m->mid_atten, m->dtype, ub.a3, ub.qkv3, ub.att3, ub.b3, B, H3, W3, st));   // -> b3
     LDM_TRY(run_resblock(m->rb[4], ub.b3, ub.c3, ub.a3, B, H3, W3, tv, st));               // mid_res2 -> a3
-    LDM_TRY(run_conv(m->up1, ub.a3, c3, nullptr, 0, ub.a2, B, H3, W3, ACT_NONE, nullptr, nullptr, 0, 0, st));
-    LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (m->have_up_fused) {
+        // up1 + cat + up_conv1 as one transposed conv over {a3, skip s2} -> b2
+        LDM_TRY(run_conv(m->up1_fused, ub.a3, c3, ub.s2, c2, ub.b2, B, H3, W3, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    } else {
+        LDM_TRY(run_conv(m->up1, ub.a3, c3, nullptr, 0, ub.a2, B, H3, W3, ACT_NONE, nullptr, nullptr, 0, 0, st));
+        LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    }
     LDM_TRY(run_resblock(m->rb[5], ub.b2, ub.a2, ub.s2, B, H2, W2, tv, st));               // up_res1 -> s2
     const void* u1 = ub.s2;
     if (m->scaled) {
         LDM_TRY(run_attention(m->up_atten, m->dtype, ub.s2, ub.qkv2, ub.att2, ub.b2, B, H2, W2, st));
         u1 = ub.b2;
     }
-    if (m->have_up2_fused && upfuse_shape_ok(m->dtype, c2, c1, c1, B, H2, W2)) {
+    if (m->have_up_fused && upfuse_shape_ok(m->dtype, c2, c1, c1, B, H2, W2)) {
         LDM_TRY(launch_upfuse(m->up2_fused, u1, ub.s1, ub.b1, B, H2, W2, st));      // up2 + cat + up_conv2 -> b1
+    } else if (m->have_up_fused) {
+        LDM_TRY(run_conv(m->up2_fused, u1, c2, ub.s1, c1, ub.b1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
     } else {
         LDM_TRY(run_conv(m->up2, u1, c2, nullptr, 0, ub.a1, B, H2, W2, ACT_NONE, nullptr, nullptr, 0, 0, st));
         LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));

@@ -169,8 +169,13 @@ __device__ __forceinline__ constexpr int tap_dx(int t) { return NTAPS == 9 ? t %
 // TH: tile rows; BN: output channels per workgroup; WM x WN waves (4 or 8) over (pixel rows, channels);
 // S: stride; KEXT: window extent (3 for 3x3 and the convT phases, 1 for 1x1); NTAPS: taps per chunk
 // (9, 4 or 1; the tap loop is unrolled); MINW: waves per SIMD the register budget must allow.
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING>
+// NT1: taps of the second source's chunks.  NT1 = NTAPS: the second source continues the channels of the
+// first (1x1 conv over a concatenation).  NT1 = 1 with NTAPS = 4: fused transposed conv + concat + 1x1; the
+// second source lives at OUTPUT resolution and contributes the pixel (2y+py, 2x+px) itself.
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING, int NT1 = NTAPS>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapConvArgs a) {
+    constexpr bool SKIPUP = NT1 != NTAPS;
+    static_assert(!SKIPUP || (NTAPS == 4 && NT1 == 1 && S == 1), "single-tap second source: transposed conv only");
     constexpr int NWV = WM * WN;
     static_assert(NWV == 4 || NWV == 8, "four or eight waves");
     constexpr int TW = 16;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const int n0 = nb * BN;
     const int iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
     const int nchunks = a.nch0 + a.nch1;
-    const int nsteps = nchunks * NTAPS;
+    const int nsteps = a.nch0 * NTAPS + a.nch1 * NT1;
     const int nhalo = nchunks > 1 ? 2 : 1;
 
     // LDS: [halo 0][halo 1 if more than one chunk][weight ring][1 KiB dump]
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
 #endif
 
     const char* in0_img = a.in0 + (size_t)img * a.Hin * a.Win * a.cin0_bytes;
-    const char* in1_img = a.in1 ? a.in1 + (size_t)img * a.Hin * a.Win * a.cin1_bytes : nullptr;
+    const char* in1_img = a.in1 ? a.in1 + (size_t)img * (SKIPUP ? a.Hout * a.Wout : a.Hin * a.Win) * a.cin1_bytes : nullptr;
     const char* wbase = a.w + (size_t)phase * a.w_phase_stride + (size_t)n0 * 32;
     const size_t wslab_stride = (size_t)a.cout * 128;   // bytes between consecutive (chunk, tap) slabs
     const size_t wplane_stride = (size_t)a.cout * 32;   // bytes between the pair planes of one slab
@@ -260,15 +265,35 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         const bool ok = grp < NG && hp < HP && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         hpix[q] = ok ? (iy * a.Win + ix) : -1;
     }
+    // single-tap second source (fused transposed conv): window position (hy, hx) holds the pixel that the
+    // phase's centre tap reads for output (hy - py, hx - px), i.e. pixel (2*gy + py, 2*gx + px) of the
+    // output-resolution tensor; every other window position is zero
+    int hpix1[SKIPUP ? NHW : 1];
+    if constexpr (SKIPUP) {
+        const int py1 = phase >> 1, px1 = phase & 1;
+#pragma unroll
+        for (int q = 0; q < NHW; ++q) {
+            const int grp = (wave + NWV * q) >> 2;
+            const int hp = grp * 32 + (lane >> 1);
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int r = hy - py1, cc = hx - px1;
+            const int gy = y0 + r, gx = x0 + cc;
+            const bool ok = grp < NG && hp < HP && r >= 0 && r < TH && cc >= 0 && cc < TW && gy < a.Hg && gx < a.Wg;
+            hpix1[q] = ok ? ((2 * gy + py1) * a.Wout + 2 * gx + px1) : -1;
+        }
+    }
     auto issue_halo = [&](int c) {
-        const char* base = (c < a.nch0 ? in0_img + c * 128 : in1_img + (c - a.nch0) * 128) + (lane & 1) * 16 +
+        const bool src1 = c >= a.nch0;
+        const char* base = (!src1 ? in0_img + c * 128 : in1_img + (c - a.nch0) * 128) + (lane & 1) * 16 +
                            (wave & 3) * 32;
-        const int pix_bytes = c < a.nch0 ? a.cin0_bytes : a.cin1_bytes;
+        const int pix_bytes = !src1 ? a.cin0_bytes : a.cin1_bytes;
         const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES + (wave & 3) * HPLANE;
 #pragma unroll
         for (int q = 0; q < NHW; ++q) {
             const int grp = (wave + NWV * q) >> 2;       // wave-uniform
-            const char* src = hpix[q] >= 0 ? base + (size_t)hpix[q] * pix_bytes : zero;
+            int pix = hpix[q];
+            if constexpr (SKIPUP) pix = src1 ? hpix1[q] : pix;
+            const char* src = pix >= 0 ? base + (size_t)pix * pix_bytes : zero;
             const unsigned dst = grp < NG ? hb + grp * 1024 : dump;
             if constexpr (!(TAPCONV_ABLATE & 16)) glds16(src, smem + dst);
         }
@@ -391,8 +416,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     for (int c = 0; c < nchunks; ++c) {
         const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES;
         const bool more_chunks = c + 1 < nchunks;
+        const int ntc = (SKIPUP && c >= a.nch0) ? NT1 : NTAPS;      // taps of this chunk
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t, ++s) {
+            if (SKIPUP && t >= ntc) break;
             // slab s+D goes to the ring slot that step s-1 read; every wave finished those reads
             // before it passed that step's barrier
             STAMP_ISSUE(tsA);
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             const int slot_next = slot + 1 == RING ? 0 : slot + 1;
             // first half of the next step (after the very last step this reads LDS that nobody uses:
             // harmless, and reads and MFMAs stay in one basic block for the interleave)
-            const bool wrap = t == NTAPS - 1;
+            const bool wrap = t == ntc - 1;
             const unsigned hbn = wrap ? hbuf0 + (more_chunks ? ((c + 1) & 1) : 0) * HALO_BYTES : hb;
             if constexpr (!(TAPCONV_ABLATE & 4)) {
                 load_frags(1, hb, wb, t, wfB, xfB);
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             const int need = s + PUB < nsteps - 1 ? s + PUB : nsteps - 1;
             const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
             const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - need > 0 ? last - need : 0);
-            const bool h_young = more_chunks && t <= D - 1 - PUB && t <= NTAPS - 1 - PUB && !(TAPCONV_ABLATE & 16);
+            const bool h_young = more_chunks && t <= D - 1 - PUB && t <= ntc - 1 - PUB && !(TAPCONV_ABLATE & 16);
 #ifdef TAPCONV_STAMP
             STAMP_ISSUE(tsB);        // (waits for the LDS reads as a side effect)
 #endif
@@ -1084,7 +1111,7 @@ int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
     LDM_FAIL(LDM_ERR_INVALID, "unknown conv kind");
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING = 3>
+template <typename T, int TH, int BN, int WM, int WN, int S, int KEXT, int NTAPS, int MINW, int RING = 3, int NT1 = NTAPS>
 static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     constexpr int NWV = WM * WN;
     constexpr int HH = (TH - 1) * S + KEXT, HW = 15 * S + KEXT;
@@ -1104,7 +1131,7 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     a.nblk_n = a.cout / BN;
     if (a.ntaps != NTAPS) LDM_FAIL(LDM_ERR_INVALID, "tap count does not match the kernel");
-    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW, RING>;
+    auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW, RING, NT1>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1209,6 +1236,21 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
     }
+    if (pc.ntaps1 != pc.ntaps) {
+        // fused transposed conv + concat + 1x1: the second source has one tap and output resolution
+        if constexpr (sizeof(T) == 2) {
+            if (pc.ntaps1 != 1 || !cc.in1) LDM_FAIL(LDM_ERR_INVALID, "fused up-sampling conv needs its skip source");
+            if (bn == 128) {
+                if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, 3, 1>(a, nph, stream);
+                if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
+                return launch_cfg<T, 4, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
+            }
+            if (th == 8 || th == 16) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 4, 2, 3, 1>(a, nph, stream);
+            return launch_cfg<T, 4, 64, 2, 2, 1, 3, 4, 2, 3, 1>(a, nph, stream);
+        } else {
+            LDM_FAIL(LDM_ERR_INVALID, "fused up-sampling conv is bf16 only");
+        }
+    }
     if (bn == 128) {
         if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2>(a, nph, stream);
         if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1>(a, nph, stream);
@@ -1224,12 +1266,12 @@ bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, in
            (long)B * (Hin / 4) * (Win / 16) >= 256 && (size_t)Hin * Win * 256 * 4 < (1ull << 31) && !TAPCONV_NO_WS64;
 }
 
-// pc: packed by pack_conv as CONVT4x4_S2 over the sources {128 composed input channels, 64 skip channels}
-// (the skip chunk's tap 0 holds the 1x1 weights, its other taps are unused)
+// pc: packed by pack_conv as CONVT4x4_S2 over the sources {128 composed input channels, 64 skip channels},
+// the skip chunk with a single tap
 int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* out, int B, int Hin, int Win,
                   hipStream_t stream) {
     LDM_REQUIRE(x && skip && out && pc.w && pc.bias, "null tensor");
-    LDM_REQUIRE(pc.kind == CONVT4x4_S2 && pc.cin == 192 && upfuse_shape_ok(pc.dtype, 128, 64, pc.cout, B, Hin, Win),
+    LDM_REQUIRE(pc.kind == CONVT4x4_S2 && pc.cin == 192 && pc.ntaps1 == 1 && upfuse_shape_ok(pc.dtype, 128, 64, pc.cout, B, Hin, Win),
                 "shape not served by the fused up-sampling kernel");
     static int ncu = 0;
     if (ncu == 0) {
@@ -1241,7 +1283,7 @@ int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* o
     a.in0 = (const char*)x; a.in1 = (const char*)skip; a.w = (const char*)pc.w; a.bias = pc.bias; a.out = (char*)out;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = 2 * Hin; a.Wout = 2 * Win; a.cout = 64;
     a.tiles_x = Win / 16; a.tiles_y = Hin / 4; a.ntiles = a.tiles_x * a.tiles_y * B;
-    a.w_phase_stride = (long)3 * 4 * 64 * 128;       // three chunks x four taps of 8-KiB slabs per phase
+    a.w_phase_stride = (long)9 * 64 * 128;           // 2 chunks x 4 taps + 1 skip slab of 8 KiB per phase
     const size_t lds = 2 * 64 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1263,6 +1305,8 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     LDM_REQUIRE(cc.B > 0 && cc.Hin > 0 && cc.Win > 0, "empty input");
     LDM_REQUIRE((cc.cin1 == 0) == (cc.in1 == nullptr), "second source and its channel count disagree");
     LDM_REQUIRE((size_t)cc.Hin * cc.Win * (size_t)(cc.cin0 > cc.cin1 ? cc.cin0 : cc.cin1) * es < (1ull << 31), "image too large");
+    if (pc.ntaps1 != pc.ntaps)   // the second source has the output's resolution
+        LDM_REQUIRE((size_t)4 * cc.Hin * cc.Win * (size_t)cc.cin1 * es < (1ull << 31), "image too large");
     TapConvArgs a{};
     a.in0 = (const char*)cc.in0; a.in1 = (const char*)cc.in1;
     a.w = (const char*)pc.w; a.bias = pc.bias;
@@ -1280,7 +1324,7 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     a.t_img_stride = cc.t_img_stride; a.t_step_stride = cc.t_step_stride;
     a.sched_z = cc.ddim_z; a.sched_coef = cc.ddim_coef; a.sched_ticket = cc.ddim_ticket;
     LDM_REQUIRE(!cc.ddim_z || (cc.ddim_coef && cc.step_ptr), "fused DDIM update needs the coefficient table and the step counter");
-    a.w_phase_stride = (long)(pc.cin / ck) * pc.ntaps * pc.cout * 128;
+    a.w_phase_stride = ((long)a.nch0 * pc.ntaps + (long)a.nch1 * pc.ntaps1) * pc.cout * 128;
     if (pc.dtype == LDM_BF16) return launch_typed<bf16_t>(pc, cc, a, stream);
     return launch_typed<float>(pc, cc, a, stream);
 }
