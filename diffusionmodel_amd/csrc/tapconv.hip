@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     // state handed from one half to the next: the finished accumulators, the loads their epilogue
     // needs, the time vector and the element offset of their first row
     f32x4 accP[NF][HR];
-    u32x4 ldP[NLDG > 0 ? NLDG : 1];
+    u32x4 ldP[NLDG > 1 ? NLDG : 2];
     size_t eP = 0;
     char* stage = smem + 2 * HALO_BYTES + wave * (NLDG * 1024);      // wave-uniform: DMA destination base
     f32x4 v0, v1;          // the row that is passing through the epilogue slices
@@ -1099,6 +1099,167 @@ __global__ __launch_bounds__(512, 1) void upfuse_ws_kernel(const TapConvArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight-stationary stride-2 convolution: conv3x3 / stride 2, 64 -> 128 channels, bf16, bias only (down2 of
+// the UNet).  The generic kernel streams 144 KiB of weights per 64 output pixels here and runs at a sixth
+// of the MFMA peak.  Same scheme as tapconv_ws64_kernel: 4 waves, wave w keeps the weights of output
+// channels 32w .. 32w+31 in 144 registers; tiles of 2 x 16 output pixels (5 x 33 input window,
+// double-buffered, columns de-interleaved into even | odd so that a fragment's 16 pixels are consecutive
+// LDS slots); a fragment (window row, column shift, channel half) is read once and serves both output
+// rows where they share the window row; the previous tile's epilogue, its stores and the next tile's DMA
+// pieces are spread over the 72 MFMAs of the current tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
+    constexpr int TR = 2, HH = 2 * TR + 1, HW = 33, HWE = 17, HP = HH * HW;      // 165 window pixels
+    constexpr int NG = (HP + 31) / 32;                                           // 6 groups of 32
+    constexpr int HPLANE = NG * 1024, HALO_BYTES = 4 * HPLANE;
+    constexpr int NF = 2, KS = 18, XD = 4, NFR = HH * 6;                         // 30 fragments per tile
+    static_assert(NG == 6, "six halo pieces per wave and tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const char* zero = (const char*)g_zero16;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
+
+    u32x4 wreg[KS][NF];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            wreg[ks][nf] = *(const u32x4*)(a.w + (ks >> 1) * 16384 + ((ks & 1) * 2 + (g >> 1)) * 4096 +
+                                           ((wave * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
+
+    // halo DMA: piece q of wave w = (group q, plane w); slot -> window pixel, columns de-interleaved
+    int hyx[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const int hp = q * 32 + (lane >> 1);
+        const int hy = hp / HW, hr = hp - hy * HW;
+        const int hx = hr < HWE ? 2 * hr : 2 * (hr - HWE) + 1;
+        hyx[q] = hp < HP ? (hy << 8 | hx) : -1;
+    }
+    const char* hbase;
+    int hiy0, hix0;
+    bool hlive;
+    auto halo_origin = [&](int t) {
+        hlive = t < a.ntiles;
+        const int tt = hlive ? t : 0;
+        const int img = tt / tiles_per_img;
+        const int trem = tt - img * tiles_per_img;
+        hiy0 = (trem / a.tiles_x) * TR * 2 - 1;
+        hix0 = (trem % a.tiles_x) * 32 - 1;
+        hbase = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
+    };
+    auto halo_piece = [&](int q, int buf) {
+        const int iy = hiy0 + (hyx[q] >> 8), ix = hix0 + (hyx[q] & 255);
+        const bool ok = hlive && hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * 128 : zero;
+        glds16(src, smem + buf * HALO_BYTES + wave * HPLANE + q * 1024);
+    };
+    halo_origin(tile);
+#pragma unroll
+    for (int q = 0; q < NG; ++q) halo_piece(q, 0);
+
+    const unsigned hlane = (g >> 1) * HPLANE + l15 * 32 + (g & 1) * 16;
+    const int co = wave * 32 + (g & 1) * 16 + (g >> 1) * 8;
+    const size_t erow = (size_t)a.Wout * 128;
+    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+
+    f32x4 accP[NF][TR];
+    size_t eP = 0;
+    auto epilogue_row = [&](int j) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[1][j][q]), false, false);
+            v0[q] = u2f(sw[0]);
+            v1[q] = u2f(sw[1]);
+        }
+        v0 += b0;
+        v1 += b1;
+        u32x4 o;
+        o[0] = pack2(v0[0], v0[1]);
+        o[1] = pack2(v0[2], v0[3]);
+        o[2] = pack2(v1[0], v1[1]);
+        o[3] = pack2(v1[2], v1[3]);
+        *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
+    };
+
+    int buf = 0;
+    size_t e0 = 0;
+    // per tile and wave: 6 DMA pieces, then the 2 stores of the previous tile's rows
+    auto tile_top = [&](auto first_tag) {
+        if (decltype(first_tag)::value) wait_vmcnt<0>();
+        else wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        halo_origin(tile + (int)gridDim.x);
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int y0 = (trem / a.tiles_x) * TR, x0 = (trem % a.tiles_x) * 16;
+        e0 = (((size_t)img * a.Hout + y0) * a.Wout + x0 + l15) * 128 + co;
+    };
+    auto do_tile = [&](auto epi_tag) {
+        constexpr bool EPI = decltype(epi_tag)::value;
+        f32x4 acc[NF][TR];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hp0 = smem + buf * HALO_BYTES + hlane;
+        // fragment f = (window row h, column shift dx, channel half kk), kk fastest
+        auto foff = [&](int f) {
+            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
+            return kk * 2 * HPLANE + (h * HW + (dx & 1) * HWE + (dx >> 1)) * 32;
+        };
+        u32x4 xf[XD];
+#pragma unroll
+        for (int f = 0; f < XD - 1; ++f) xf[f] = *(const u32x4*)(hp0 + foff(f));
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+            if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *(const u32x4*)(hp0 + foff(f + XD - 1));
+            if (f < NG) halo_piece(f, buf ^ 1);
+            if (f == NG) asm volatile("" ::: "memory");
+            if (EPI && f == 14) epilogue_row(0);
+            if (EPI && f == 26) epilogue_row(1);
+            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const int dy = h - 2 * r;
+                if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wreg[(dy * 3 + dx) * 2 + kk][nf]), __builtin_bit_cast(bf16x8, xf[f % XD]),
+                        acc[nf][r], 0, 0, 0);
+            }
+            if (f + XD - 1 < NFR) {
+                if (h == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) accP[nf][r] = acc[nf][r];
+        eP = e0;
+    };
+
+    tile_top(BoolC<true>{});
+    do_tile(BoolC<false>{});
+    tile += gridDim.x;
+    buf ^= 1;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        tile_top(BoolC<false>{});
+        do_tile(BoolC<true>{});
+    }
+    epilogue_row(0);
+    epilogue_row(1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -1182,6 +1343,28 @@ bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
            (long)(H / 8) * (W / 16) * B >= 512 && !TAPCONV_NO_WS64;
 }
 
+static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
+    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 128 && a.Hin % 4 == 0 &&
+           a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
+}
+
+static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        LDM_HIP(hipGetDevice(&dev));
+        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    a.tiles_x = a.Wout / 16;
+    a.tiles_y = a.Hout / 2;
+    a.ntiles = a.tiles_x * a.tiles_y * a.B;
+    const size_t lds = 2 * 6 * 4096;                 // two windows of 5 x 33 pixels
+    const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+    hipLaunchKernelGGL(s2ws_kernel, dim3(grid), dim3(256), lds, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     const int bn = (a.cout % 128 == 0) ? 128 : 64;
@@ -1197,6 +1380,9 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         }
     }
     if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
+    if constexpr (sizeof(T) == 2) {
+        if (s2ws_shape(pc, a) && a.act == ACT_NONE && !a.res && !a.tvec && !a.out_f32) return launch_s2ws(a, stream);
+    }
     const int nblk_n = a.cout / bn;
     const long tx = (a.Wg + 15) / 16;
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;
