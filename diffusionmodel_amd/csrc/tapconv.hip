@@ -1260,6 +1260,152 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight-stationary 1x1 convolution (token Linear): 256 input channels, output channels in blocks of 256,
+// bf16, bias (+ residual).  The fused q|k|v projection of Attention (256 -> 768) is 6.4 GFLOP at B=64; the
+// generic kernel re-stages every 256-pixel window once per 128-channel block and spends its time in
+// prologues and epilogues (four steps per workgroup).  Here a workgroup of 4 waves owns 256 output
+// channels (wave w: 64 of them, 8 half steps x 4 fragments = 128 weight registers) and walks over tiles of
+// 32 consecutive pixels of the flattened [B*H*W, 256] activation; tiles are double-buffered in LDS
+// (4 DMA pieces per wave), and the previous tile's epilogue and stores are spread over the 64 MFMAs of
+// the current one, as in the 3x3 kernels above.
+// ---------------------------------------------------------------------------------------------
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
+    constexpr int TR = 2, NF = 4, KS = 8, XD = 4, NFR = TR * KS;        // 16 fragments, 64 MFMAs per tile
+    constexpr int TILE_BYTES = TR * 16 * 512;                           // 32 pixels x 512 bytes
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const char* zero = (const char*)g_zero16;
+    // workgroup -> (block of 256 output channels, first tile, tile stride); a.nblk_n = workgroups per block
+    const int cb = blockIdx.x / a.nblk_n, first = blockIdx.x % a.nblk_n;
+    int tile = first;
+
+    u32x4 wreg[KS][NF];
+    const size_t slab = (size_t)a.cout * 128;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            wreg[ks][nf] = *(const u32x4*)(a.w + (ks >> 1) * slab +
+                                           ((size_t)((ks & 1) * 2 + (g >> 1)) * a.cout + cb * 256 + wave * 64 + nf * 16 + l15) * 32 +
+                                           (g & 1) * 16);
+
+    // tile DMA: wave w stages channel chunk w (128 bytes of every pixel), one piece per pair plane
+    auto issue_tile = [&](int t, int buf) {
+        const bool live = t < a.ntiles;
+        const char* src0 = a.in0 + ((size_t)(live ? t : 0) * 32 + (lane >> 1)) * 512 + wave * 128 + (lane & 1) * 16;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16(live ? src0 + p * 32 : zero, smem + buf * TILE_BYTES + wave * 4096 + p * 1024);
+    };
+    issue_tile(tile, 0);
+
+    const unsigned xlane = (g >> 1) * 1024 + l15 * 32 + (g & 1) * 16;
+    // after the lane swap a lane owns 8 consecutive channels: pair j covers fragments 2j, 2j+1
+    const int co0 = cb * 256 + wave * 64 + (g & 1) * 16 + (g >> 1) * 8;
+    f32x4 bia[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bia[j][0] = *(const f32x4*)(a.bias + co0 + j * 32);
+        bia[j][1] = *(const f32x4*)(a.bias + co0 + j * 32 + 4);
+    }
+
+    f32x4 accP[NF][TR];
+    size_t eP = 0;
+    // epilogue unit u = (row u >> 1, channel pair u & 1)
+    auto epilogue_unit = [&](int u) {
+        const int r = u >> 1, j = u & 1;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[2 * j][r][q]), f2u(accP[2 * j + 1][r][q]), false, false);
+            v0[q] = u2f(sw[0]);
+            v1[q] = u2f(sw[1]);
+        }
+        v0 += bia[j][0];
+        v1 += bia[j][1];
+        const size_t eo = eP + (size_t)r * 16 * a.cout + j * 32;
+        if (RES) {
+            const u32x4 rr = *(const u32x4*)(a.res + eo * 2);
+            const unsigned int u0 = rr[0], u1 = rr[1], u2 = rr[2], u3 = rr[3];
+            v0[0] += bf2f((bf16_t)(u0 & 0xffffu)); v0[1] += bf2f((bf16_t)(u0 >> 16));
+            v0[2] += bf2f((bf16_t)(u1 & 0xffffu)); v0[3] += bf2f((bf16_t)(u1 >> 16));
+            v1[0] += bf2f((bf16_t)(u2 & 0xffffu)); v1[1] += bf2f((bf16_t)(u2 >> 16));
+            v1[2] += bf2f((bf16_t)(u3 & 0xffffu)); v1[3] += bf2f((bf16_t)(u3 >> 16));
+        }
+        u32x4 o;
+        o[0] = pack2(v0[0], v0[1]);
+        o[1] = pack2(v0[2], v0[3]);
+        o[2] = pack2(v1[0], v1[1]);
+        o[3] = pack2(v1[2], v1[3]);
+        *(u32x4*)(a.out + eo * 2) = o;
+    };
+
+    int buf = 0;
+    size_t e0 = 0;
+    // per tile and wave: 4 DMA pieces, then the 4 stores of the previous tile.  With a residual the
+    // epilogue's plain loads make the compiler drain the queue itself; the counted wait is then moot.
+    auto tile_top = [&](auto first_tag) {
+        if (decltype(first_tag)::value || RES) wait_vmcnt<0>();
+        else wait_vmcnt<4>();
+        __builtin_amdgcn_s_barrier();
+        e0 = ((size_t)tile * 32 + l15) * a.cout + co0;
+    };
+    auto do_tile = [&](auto epi_tag) {
+        constexpr bool EPI = decltype(epi_tag)::value;
+        f32x4 acc[NF][TR];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* xp = smem + buf * TILE_BYTES + xlane;
+        // fragment f = (row r, half step ks): chunk ks >> 1, planes (ks & 1) * 2 + g / 2
+        auto foff = [&](int f) {
+            const int r = f / KS, ks = f % KS;
+            return (ks >> 1) * 4096 + (ks & 1) * 2048 + r * 512;
+        };
+        u32x4 xf[XD];
+#pragma unroll
+        for (int f = 0; f < XD - 1; ++f) xf[f] = *(const u32x4*)(xp + foff(f));
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+            if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *(const u32x4*)(xp + foff(f + XD - 1));
+            if (f == 0) issue_tile(tile + a.nblk_n, buf ^ 1);
+            if (f == 1) asm volatile("" ::: "memory");
+            if (EPI && (f & 3) == 3) epilogue_unit(f >> 2);
+            const int r = f / KS, ks = f % KS;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wreg[ks][nf]), __builtin_bit_cast(bf16x8, xf[f % XD]), acc[nf][r], 0, 0, 0);
+            if (f + XD - 1 < NFR) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) accP[nf][r] = acc[nf][r];
+        eP = e0;
+    };
+
+    if (tile >= a.ntiles) return;     // (not reached: the launcher starts at most one workgroup per tile and block)
+    tile_top(BoolC<true>{});
+    do_tile(BoolC<false>{});
+    tile += a.nblk_n;
+    buf ^= 1;
+    for (; tile < a.ntiles; tile += a.nblk_n, buf ^= 1) {
+        tile_top(BoolC<false>{});
+        do_tile(BoolC<true>{});
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) epilogue_unit(u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -1365,6 +1511,31 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     return LDM_OK;
 }
 
+static bool ws1x1_shape(const PackedConv& pc, const TapConvArgs& a) {
+    const long px = (long)a.B * a.Hin * a.Win;
+    return pc.dtype == LDM_BF16 && pc.kind == CONV1x1 && a.nch0 == 4 && a.nch1 == 0 && a.cout % 256 == 0 && px % 32 == 0 &&
+           px / 32 >= 512 && !TAPCONV_NO_WS64;
+}
+
+template <bool RES>
+static int launch_ws1x1(TapConvArgs& a, hipStream_t stream) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        LDM_HIP(hipGetDevice(&dev));
+        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int ncb = a.cout / 256;
+    a.ntiles = (int)((long)a.B * a.Hin * a.Win / 32);
+    int per = 2 * ncu / ncb;                       // workgroups per block of 256 output channels
+    if (per > a.ntiles) per = a.ntiles;
+    a.nblk_n = per;
+    const size_t lds = 2 * 16 * 1024;              // two tiles of 32 pixels x 512 bytes
+    hipLaunchKernelGGL(ws1x1_kernel<RES>, dim3((unsigned)(per * ncb)), dim3(256), lds, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     const int bn = (a.cout % 128 == 0) ? 128 : 64;
@@ -1382,6 +1553,8 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
     if constexpr (sizeof(T) == 2) {
         if (s2ws_shape(pc, a) && a.act == ACT_NONE && !a.res && !a.tvec && !a.out_f32) return launch_s2ws(a, stream);
+        if (ws1x1_shape(pc, a) && a.act == ACT_NONE && !a.tvec && !a.out_f32)
+            return a.res ? launch_ws1x1<true>(a, stream) : launch_ws1x1<false>(a, stream);
     }
     const int nblk_n = a.cout / bn;
     const long tx = (a.Wg + 15) / 16;
