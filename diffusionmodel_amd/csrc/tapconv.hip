@@ -1190,9 +1190,10 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
     int buf = 0;
     size_t e0 = 0;
     // per tile and wave: 6 DMA pieces, then the 2 stores of the previous tile's rows
-    auto tile_top = [&](auto first_tag) {
-        if (decltype(first_tag)::value) wait_vmcnt<0>();
-        else wait_vmcnt<2>();
+    // (the first tile has no previous rows to store: after it nothing is younger than its DMA pieces)
+    auto tile_top = [&](bool stores_behind) {
+        if (stores_behind) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         halo_origin(tile + (int)gridDim.x);
         const int img = tile / tiles_per_img;
@@ -1247,13 +1248,15 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
         eP = e0;
     };
 
-    tile_top(BoolC<true>{});
+    tile_top(false);
     do_tile(BoolC<false>{});
     tile += gridDim.x;
     buf ^= 1;
+    bool stores_behind = false;
     for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
-        tile_top(BoolC<false>{});
+        tile_top(stores_behind);
         do_tile(BoolC<true>{});
+        stores_behind = true;
     }
     epilogue_row(0);
     epilogue_row(1);
@@ -1347,9 +1350,10 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
     size_t e0 = 0;
     // per tile and wave: 4 DMA pieces, then the 4 stores of the previous tile.  With a residual the
     // epilogue's plain loads make the compiler drain the queue itself; the counted wait is then moot.
-    auto tile_top = [&](auto first_tag) {
-        if (decltype(first_tag)::value || RES) wait_vmcnt<0>();
-        else wait_vmcnt<4>();
+    // (the first tile has no previous tile to store: after it nothing is younger than its DMA pieces)
+    auto tile_top = [&](bool stores_behind) {
+        if (stores_behind && !RES) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         e0 = ((size_t)tile * 32 + l15) * a.cout + co0;
     };
@@ -1393,13 +1397,15 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
     };
 
     if (tile >= a.ntiles) return;     // (not reached: the launcher starts at most one workgroup per tile and block)
-    tile_top(BoolC<true>{});
+    tile_top(false);
     do_tile(BoolC<false>{});
     tile += a.nblk_n;
     buf ^= 1;
+    bool stores_behind = false;
     for (; tile < a.ntiles; tile += a.nblk_n, buf ^= 1) {
-        tile_top(BoolC<false>{});
+        tile_top(stores_behind);
         do_tile(BoolC<true>{});
+        stores_behind = true;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) epilogue_unit(u);
