@@ -15,6 +15,7 @@
 // LDS rows are XOR-swizzled per 16-byte piece (K: piece ^ (row & 15); V: piece ^ ((row & 7) << 1)) on the
 // DMA source address and on the reads alike.
 #include "common.h"
+#include <utility>
 
 namespace ldm {
 
@@ -31,6 +32,13 @@ __device__ __forceinline__ float at_u2f(unsigned int u) { return __builtin_bit_c
 __device__ __forceinline__ unsigned int at_pack2(float a, float b) {
     return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)a) |
            ((unsigned int)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+// the same rounding as one v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float at_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 at_bf16x2;
+__device__ __forceinline__ unsigned int at_pack2v(float a, float b) {
+    const at_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, at_bf16x2));
 }
 
 template <typename T, int D, int QF, int KF, int MINB>
@@ -250,6 +258,279 @@ __global__ __launch_bounds__(256, MINB) void attention_kernel(const char* __rest
     }
 }
 
+template <int N_>
+__device__ __forceinline__ void at_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+// LDS reads that the compiler neither reorders among themselves nor waits for: the caller pairs each
+// with at_wait_lgkm<N>(value) (N = LDS instructions issued after the read that may still be in flight;
+// LDS instructions return in order) before the first use of the value.  Two reasons to bypass the
+// compiler here: short of registers it waits for every read right before the two MFMAs it feeds, and
+// before a transposing read it drains every LDS-DMA in flight.
+template <int OFF>
+__device__ __forceinline__ u32x4 at_lds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint2 at_lds_read_tr16(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N_>
+__device__ __forceinline__ void at_wait_lgkm(u32x4& v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N_));
+}
+template <int... I, class F>
+__device__ __forceinline__ void at_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, class F>
+__device__ __forceinline__ void at_static_for(F&& f) {
+    at_static_for_impl(std::make_integer_sequence<int, N_>{}, f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long-sequence variant (bf16, N a multiple of 32, thousands of keys per query): same arithmetic as
+// attention_kernel, organised for throughput.  8 waves (two per SIMD) x QF*16 queries share every
+// 32-key K/V tile, so a tile crosses L2 -> LDS once per 128*QF queries.  Tiles go through a ring of four
+// stages and are issued two intervals ahead; waits on the DMA are counted (only the newest pieces may be in
+// flight), LDS fragment reads are ordered inline-asm reads with counted waits (a register ring three deep).
+// (Running the second wave of every SIMD half an interval out of phase, so that one wave's exponentials
+// overlap the other's MFMAs, measured no faster.)
+// ---------------------------------------------------------------------------------------------
+#ifndef ATTN_STREAM_XD
+#define ATTN_STREAM_XD 3
+#endif
+template <int D, int QF>
+__global__ __launch_bounds__(512, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
+                                                               int N, float scale_log2e) {
+    constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
+    constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NW = 8, NST = 4;
+    constexpr int QB = NW * QF * 16, PPT = NPIECE / NW, PPW = 2 * PPT;
+    static_assert(NPIECE % NW == 0, "every wave issues the same number of pieces");
+    static_assert(NST * 2 * TILE <= 160 * 1024, "LDS budget");
+    constexpr float RESCALE_LOG2 = 8.0f;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * QB + wave * QF * 16;
+    const char* base = qkv + (size_t)b * N * 3 * RB;
+    const int ntiles = N / KT;
+
+    // DMA pieces of this wave: piece i = wave + 8 j covers rows i * (1024 / RB) ... of the tile; pieces j > 0
+    // lie a whole number of 16-row groups below piece 0 (same swizzle), so they differ only in the
+    // wave-uniform base.  One 32-bit lane offset per matrix.
+    static_assert((NW * 1024 / RB) % 16 == 0, "pieces of one wave share the swizzle");
+    unsigned koff, voff;
+    {
+        const int o = wave * 1024 + lane * 16;
+        const int r = o / RB, sp = (o - r * RB) >> 4;
+        koff = r * 3 * RB + RB + ((sp ^ (r & 15)) << 4);
+        voff = r * 3 * RB + 2 * RB + ((sp ^ ((r & 7) << 1)) << 4);
+    }
+    auto issue_tile = [&](int t) {
+        char* kd = smem + (t & (NST - 1)) * 2 * TILE + wave * 1024;
+        const char* src = base + (size_t)t * KT * 3 * RB;
+        unsigned ko = koff, vo = voff;
+        asm volatile("" : "+v"(ko), "+v"(vo));   // opaque: no per-piece 64-bit addresses kept across iterations
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const char* sj = src + (size_t)j * (NW * 1024 / RB) * 3 * RB;
+            at_glds16(sj + ko, kd + j * NW * 1024);
+            at_glds16(sj + vo, kd + TILE + j * NW * 1024);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < ntiles) issue_tile(t);
+
+    u32x4 qreg[QF][KS];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        const char* row = base + (size_t)(q0 + qf * 16 + l15) * 3 * RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qreg[qf][ks] = *(const u32x4*)(row + (ks * 4 + g) * 16);
+    }
+    // a use of the loaded registers: the compiler waits for the loads here and not at the top of the
+    // tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qreg[qf][ks]));
+
+    f32x4 oacc[DF][QF];
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) oacc[df][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QF], lrun[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) { mrun[qf] = -1e30f; lrun[qf] = 0.f; }
+
+    f32x4 sacc[KF][QF];
+    u32x4 pb[QF];
+    // LDS read addresses: everything that depends on the lane in one register per matrix, the fragment
+    // index enters by XOR on bits the lane part may also set (computed per read: a table of
+    // addresses per fragment would cost the registers the accumulators need) plus an immediate.
+    const unsigned klane = l15 * RB + ((((l15 >> 2) << 2) | (g ^ (l15 & 3))) << 4);
+    const int tq = l15 >> 2, tp = l15 & 3;
+    const int row0 = g * 4 + tq;
+    const unsigned vlane = TILE + row0 * RB + ((((row0 & 7) << 1) | (tp >> 1)) << 4) + (tp & 1) * 8;
+
+    // Fragment f = (ks, kf) of the K tile / df of the V tile goes through a register ring XD deep: the read
+    // of fragment f + XD - 1 is issued before the wait for fragment f.
+    constexpr int XD = ATTN_STREAM_XD, NFK = KS * KF;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto s_phase = [&](int t) {
+        const unsigned kb = lds0 + (unsigned)(t & (NST - 1)) * 2 * TILE + klane;
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) sacc[kf][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // piece (ks*4 + g) ^ l15 of row kf*16 + l15
+        auto kread = [&](auto fc) {
+            constexpr int f = decltype(fc)::value, ks = f >> 1, kf = f & 1;
+            return at_lds_read128<(ks >> 2) * 256 + kf * 16 * RB>(kb ^ ((ks & 3) << 6));
+        };
+        u32x4 kr[XD];
+        at_static_for<XD - 1>([&](auto fc) { kr[decltype(fc)::value] = kread(fc); });
+        at_static_for<NFK>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f + XD - 1 < NFK) kr[(f + XD - 1) % XD] = kread(std::integral_constant<int, f + XD - 1>{});
+            at_wait_lgkm<(NFK - 1 - f < XD - 1 ? NFK - 1 - f : XD - 1)>(kr[f % XD]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf)
+                sacc[f & 1][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, kr[f % XD]), __builtin_bit_cast(bf16x8, qreg[qf][f >> 1]), sacc[f & 1][qf], 0, 0, 0);
+        });
+    };
+    // lane holds keys kf*16 + g*4 + r of query column l15; statistics in the log2 domain
+    auto softmax = [&]() {
+        float alpha[QF];
+        bool moved = false;
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kf][qf][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= scale_log2e;                       // the scale is positive: max commutes with it
+            const bool move = mx > mrun[qf] + RESCALE_LOG2;
+            const float mnew = move ? mx : mrun[qf];
+            alpha[qf] = move ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : 1.0f;
+            moved |= move;
+            mrun[qf] = mnew;
+            float p[KF][4];
+            float rs = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kf][qf][r], scale_log2e, -mnew));
+                    rs += p[kf][r];
+                }
+            lrun[qf] = lrun[qf] * alpha[qf] + rs;    // per-lane partial; the 4 key groups are summed at the end
+            pb[qf][0] = at_pack2v(p[0][0], p[0][1]);
+            pb[qf][1] = at_pack2v(p[0][2], p[0][3]);
+            pb[qf][2] = at_pack2v(p[1][0], p[1][1]);
+            pb[qf][3] = at_pack2v(p[1][2], p[1][3]);
+        }
+        if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {      // wave-uniform, rare after the first tiles
+#pragma unroll
+            for (int df = 0; df < DF; ++df)
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) oacc[df][qf] *= alpha[qf];
+        }
+    };
+    auto pv_phase = [&](int t) {
+        const unsigned vb = lds0 + (unsigned)(t & (NST - 1)) * 2 * TILE + vlane;
+        // piece (df*2 + (tp>>1)) ^ ((row & 7) << 1) of rows row0 and row0 + 16: two transposing reads
+        auto vread = [&](auto dc) {
+            constexpr int df = decltype(dc)::value;
+            const unsigned a0 = vb ^ ((df & 7) << 5);
+            const uint2 v0 = at_lds_read_tr16<(df >> 3) * 256>(a0);
+            const uint2 v1 = at_lds_read_tr16<(df >> 3) * 256 + 16 * RB>(a0);
+            return u32x4{v0.x, v0.y, v1.x, v1.y};
+        };
+        u32x4 vr[XD];
+        at_static_for<XD - 1>([&](auto dc) { vr[decltype(dc)::value] = vread(dc); });
+        at_static_for<DF>([&](auto dc) {
+            constexpr int df = decltype(dc)::value;
+            if constexpr (df + XD - 1 < DF) vr[(df + XD - 1) % XD] = vread(std::integral_constant<int, df + XD - 1>{});
+            at_wait_lgkm<2 * (DF - 1 - df < XD - 1 ? DF - 1 - df : XD - 1)>(vr[df % XD]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf)
+                oacc[df][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, vr[df % XD]), __builtin_bit_cast(bf16x8, pb[qf]), oacc[df][qf], 0, 0, 0);
+        });
+    };
+    // End of interval t: every wave is past barrier t-1, so stage (t-1) % 4 is free for tile t+3; then
+    // wait for this wave's pieces of tile t+2 (all but the ones just issued) and meet the other waves.
+    auto tail = [&](int t) {
+        if (t + NST - 1 < ntiles) {
+            issue_tile(t + NST - 1);
+            at_wait_vmcnt<PPW>();
+        } else {
+            at_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+
+    at_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < ntiles; ++t) {
+        s_phase(t);
+        softmax();
+        pv_phase(t);
+        tail(t);
+    }
+
+    // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        float l = lrun[qf];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        char* orow = out + ((size_t)b * N + q0 + qf * 16 + l15) * RB;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const f32x4 v = oacc[df][qf] * inv;
+            uint2 w;
+            w.x = at_pack2(v[0], v[1]);
+            w.y = at_pack2(v[2], v[3]);
+            *(uint2*)(orow + (df * 16 + g * 4) * 2) = w;
+        }
+    }
+}
+
+template <int D, int QF>
+static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream) {
+    constexpr int QB = 8 * QF * 16;
+    constexpr size_t lds = (size_t)4 * 2 * 32 * D * 2;
+    auto kern = attention_stream_kernel<D, QF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+    dim3 grid((unsigned)(N / QB), (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 template <typename T, int D, int QF, int KF, int MINB = 1>
 static int launch_attn_cfg(const void* qkv, void* out, int B, int N, hipStream_t stream) {
     constexpr int TILE = KF * 16 * D * (int)sizeof(T);
@@ -277,6 +558,7 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
             case 128: return launch_attn_cfg<bf16_t, 128, 2, 2>(qkv, out, B, N, stream);
             case 256:
                 // 16 queries per wave while that still leaves every CU a workgroup; O then stays in VGPRs
+                if (N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256) return launch_attn_stream<256, 2>(qkv, out, B, N, stream);
                 if ((long)B * ((N + 127) / 128) < 256) return launch_attn_cfg<bf16_t, 256, 1, 2, 2>(qkv, out, B, N, stream);
                 return launch_attn_cfg<bf16_t, 256, 2, 2>(qkv, out, B, N, stream);
             case 512: return launch_attn_cfg<bf16_t, 512, 1, 2>(qkv, out, B, N, stream);

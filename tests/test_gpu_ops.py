@@ -97,9 +97,10 @@ def test_resblock(A, O, dtype, C, B, H, W):
 # ---- Attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,B,H,W", [(256, 2, 4, 4), (256, 2, 16, 16), (128, 1, 12, 20), (256, 1, 1, 1), (512, 1, 8, 8),
-                                      (256, 64, 16, 16)])
+                                      (256, 64, 16, 16), (256, 64, 32, 32)])
 def test_attention(A, O, dtype, C, B, H, W):
     # (256, 64, 16, 16): enough tokens for the weight-stationary 1x1 kernels of the projections (bf16)
+    # (256, 64, 32, 32): 1024 tokens x 256 workgroups of 256 queries: the long-sequence attention kernel (bf16)
     from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
     w = synthetic_from_shapes(attention_param_shapes(C), 5)
     torch.manual_seed(2)
@@ -113,6 +114,24 @@ def test_attention(A, O, dtype, C, B, H, W):
     _say(f"  rel_err={e:.3e} branch={e_branch:.3e}")
     assert e < TOL[dtype]
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
+
+
+@pytest.mark.parametrize("spike_at", [5, 600, 1023])
+def test_attention_running_max_jump_long_sequence(A, O, spike_at):
+    """The same property on the long-sequence kernel (bf16, 1024 tokens, 64 images)."""
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    C, B, H, W = 256, 64, 32, 32
+    w = synthetic_from_shapes(attention_param_shapes(C), 6)
+    torch.manual_seed(40 + spike_at)
+    x = torch.randn(B, C, H, W)
+    x[:, :, spike_at // W, spike_at % W] *= 12.0
+    ref = O.attention({"m." + k: v for k, v in w.items()}, "m", x)
+    _say(f"attention spike bf16 long sequence at token {spike_at}")
+    got = A.Attention(C, dtype="bf16", weights=w)(x.cuda())
+    torch.cuda.synchronize()
+    e_branch = rel_err(got - x.cuda(), ref - x)
+    _say(f"  branch rel_err={e_branch:.3e}")
+    assert e_branch < 3e-2
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
