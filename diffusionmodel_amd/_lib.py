@@ -11,7 +11,7 @@ from typing import Optional
 LDM_OK = 0
 LDM_F32, LDM_BF16 = 0, 1
 LDM_DDPM, LDM_DDIM = 0, 1
-LDM_MOD_UNET, LDM_MOD_RESBLOCK, LDM_MOD_ATTENTION, LDM_MOD_TIME_ADDITION = 0, 1, 2, 3
+LDM_MOD_UNET, LDM_MOD_RESBLOCK, LDM_MOD_ATTENTION, LDM_MOD_TIME_ADDITION, LDM_MOD_VAE_DECODER = 0, 1, 2, 3, 4
 
 _LIB_NAME = "libldm_hip.so"
 _lib: Optional[C.CDLL] = None
@@ -38,6 +38,9 @@ SIGNATURES = {
     "ldm_resblock_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_time_addition_forward": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "ldm_vae_decoder_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "ldm_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "ldm_to_rgb8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ldm_conv_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "ldm_conv_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldm_conv_destroy": (None, [_vp]),

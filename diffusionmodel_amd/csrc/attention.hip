@@ -304,11 +304,14 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 #ifndef ATTN_STREAM_XD
 #define ATTN_STREAM_XD 3
 #endif
-template <int D, int QF>
-__global__ __launch_bounds__(512, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
-                                                               int N, float scale_log2e) {
+#ifndef ATTN_STREAM_SMALL
+#define ATTN_STREAM_SMALL 1
+#endif
+template <int D, int QF, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
+                                                                  int N, float scale_log2e) {
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
-    constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NW = 8, NST = 4;
+    constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4;
     constexpr int QB = NW * QF * 16, PPT = NPIECE / NW, PPW = 2 * PPT;
     static_assert(NPIECE % NW == 0, "every wave issues the same number of pieces");
     static_assert(NST * 2 * TILE <= 160 * 1024, "LDS budget");
@@ -323,10 +326,11 @@ __global__ __launch_bounds__(512, 1) void attention_stream_kernel(const char* __
     const char* base = qkv + (size_t)b * N * 3 * RB;
     const int ntiles = N / KT;
 
-    // DMA pieces of this wave: piece i = wave + 8 j covers rows i * (1024 / RB) ... of the tile; pieces j > 0
-    // lie a whole number of 16-row groups below piece 0 (same swizzle), so they differ only in the
-    // wave-uniform base.  One 32-bit lane offset per matrix.
-    static_assert((NW * 1024 / RB) % 16 == 0, "pieces of one wave share the swizzle");
+    // DMA pieces of this wave: piece i = wave + NW j covers the RPP rows from row i * RPP of the tile; piece j
+    // lies j * NW * RPP rows below piece 0, which changes the row swizzle by an XOR on bits that piece 0's row
+    // leaves clear.  One 32-bit lane offset per matrix.
+    constexpr int RPP = 1024 / RB, RPJ = NW * RPP;
+    static_assert(RPJ <= 16 && (RPJ & (RPJ - 1)) == 0, "row step between the pieces of one wave");
     unsigned koff, voff;
     {
         const int o = wave * 1024 + lane * 16;
@@ -341,9 +345,9 @@ __global__ __launch_bounds__(512, 1) void attention_stream_kernel(const char* __
         asm volatile("" : "+v"(ko), "+v"(vo));   // opaque: no per-piece 64-bit addresses kept across iterations
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const char* sj = src + (size_t)j * (NW * 1024 / RB) * 3 * RB;
-            at_glds16(sj + ko, kd + j * NW * 1024);
-            at_glds16(sj + vo, kd + TILE + j * NW * 1024);
+            const char* sj = src + (size_t)j * RPJ * 3 * RB;
+            at_glds16(sj + (ko ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
+            at_glds16(sj + (vo ^ ((unsigned)((j * RPJ) & 7) << 5)), kd + TILE + j * NW * 1024);
         }
     };
 #pragma unroll
@@ -514,19 +518,20 @@ __global__ __launch_bounds__(512, 1) void attention_stream_kernel(const char* __
     }
 }
 
-template <int D, int QF>
+template <int D, int QF, int NW>
 static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream) {
-    constexpr int QB = 8 * QF * 16;
+    constexpr int QB = NW * QF * 16;
     constexpr size_t lds = (size_t)4 * 2 * 32 * D * 2;
-    auto kern = attention_stream_kernel<D, QF>;
+    auto kern = attention_stream_kernel<D, QF, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     dim3 grid((unsigned)(N / QB), (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }
@@ -558,7 +563,10 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
             case 128: return launch_attn_cfg<bf16_t, 128, 2, 2>(qkv, out, B, N, stream);
             case 256:
                 // 16 queries per wave while that still leaves every CU a workgroup; O then stays in VGPRs
-                if (N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256) return launch_attn_stream<256, 2>(qkv, out, B, N, stream);
+                if (N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256) return launch_attn_stream<256, 2, 8>(qkv, out, B, N, stream);
+#if ATTN_STREAM_SMALL
+                if (N % 64 == 0 && (long)B * ((N + 127) / 128) < 256) return launch_attn_stream<256, 1, 4>(qkv, out, B, N, stream);
+#endif
                 if ((long)B * ((N + 127) / 128) < 256) return launch_attn_cfg<bf16_t, 256, 1, 2, 2>(qkv, out, B, N, stream);
                 return launch_attn_cfg<bf16_t, 256, 2, 2>(qkv, out, B, N, stream);
             case 512: return launch_attn_cfg<bf16_t, 512, 1, 2>(qkv, out, B, N, stream);

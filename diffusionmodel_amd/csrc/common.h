@@ -59,7 +59,7 @@ inline float host_bf2f(bf16_t h) {
 // convT4x4/stride 2, and conv1x1 over up to two channel-concatenated sources.
 // ---------------------------------------------------------------------------------------------
 enum ConvKind { CONV3x3_S1 = 0, CONV3x3_S2 = 1, CONVT4x4_S2 = 2, CONV1x1 = 3 };
-enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_TANH = 3 };
 
 // A convolution with its BatchNorm folded in, packed for the kernel (device memory).
 struct PackedConv {
@@ -123,6 +123,15 @@ int launch_nhwc_to_nchw(const void* in, int in_dtype, float* out, int B, int C, 
 // out[r, :] = act(in[r, :] @ W + b), W [K,N] f32 row-major; plain f32 FMA (time path, tiny)
 int launch_linear_f32(const float* in, const float* W, const float* b, float* out, int rows, int K, int N, int act,
                       hipStream_t s);
+// out[r, n] = act(sum_k in[r,k] W[k,n] + b[n]) for a wide Linear whose weights dominate the bytes (the VAE
+// decoder's transfer layer, src/main.rs:111,151-152): in f32 [rows,K], out bf16 [rows,N], wp = the weights
+// as bf16 MFMA fragments [N/16][K/32][64 lanes][8] (lane (n & 15, g): W[ks*32 + g*8 + e][nt*16 + (n & 15)]).
+// K a multiple of 128 and <= 1024, N a multiple of 16.
+int launch_linear_bf16(const float* in, const void* wp, const float* b, void* out, int rows, int K, int N, int act,
+                       hipStream_t s);
+// NCHW f32 [B,C,H,W] in [-1,1] -> HWC u8 [B,H,W,C]: ((v + 1) * 127.5) clamped to [0,255], truncated
+// (save_as_image, src/main.rs:1297-1308)
+int launch_to_rgb8(const float* in, unsigned char* out, int B, int C, int H, int W, hipStream_t s);
 // sinusoidal embedding of integer timesteps (src/main.rs:309-335)
 int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s);
 

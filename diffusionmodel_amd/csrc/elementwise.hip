@@ -370,6 +370,135 @@ int launch_linear_f32(const float* in, const float* W, const float* b, float* ou
     return LDM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide Linear, weight-bandwidth bound (VAE decoder transfer layer: 1024 -> 32768, 64 MiB of bf16 weights
+// for at most a few dozen rows).  D^T = W^T X^T on v_mfma_f32_16x16x32_bf16: the weights are the A operand,
+// stored in fragment order so that a wave streams them from HBM in 1-KiB loads and every byte is read
+// once; up to 64 input rows sit in LDS as bf16 (rows XOR-swizzled per 16-byte piece) and are the B operand.
+// A wave owns 16 output columns at a time and all of K; more than 64 rows take another pass over the weights.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lin_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lin_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int lin_pack2(float a, float b) {
+    const lin_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, lin_bf16x2));
+}
+
+__global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __restrict__ in, const char* __restrict__ wp,
+                                                             const float* __restrict__ bias, char* __restrict__ out,
+                                                             int rows, int K, int N, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int KS = K / 32, PPR = K / 8;           // k-steps; 16-byte pieces per row
+    const int RB = K * 2;
+    for (int m0 = 0; m0 < rows; m0 += 64) {
+        if (m0) __syncthreads();
+        for (int idx = tid; idx < 64 * PPR; idx += 256) {
+            const int m = idx / PPR, p = idx - m * PPR;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+            if (m0 + m < rows) {
+                const float* src = in + (size_t)(m0 + m) * K + p * 8;
+                lo = *(const f32x4*)src;
+                hi = *(const f32x4*)(src + 4);
+            }
+            u32x4 v;
+            v[0] = lin_pack2(lo[0], lo[1]); v[1] = lin_pack2(lo[2], lo[3]);
+            v[2] = lin_pack2(hi[0], hi[1]); v[3] = lin_pack2(hi[2], hi[3]);
+            *(u32x4*)(smem_raw + m * RB + ((p ^ (m & 15)) << 4)) = v;
+        }
+        __syncthreads();
+        for (int nt = blockIdx.x * 4 + wave; nt < N / 16; nt += gridDim.x * 4) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* wt = wp + (size_t)nt * KS * 1024 + lane * 16;
+            for (int ks0 = 0; ks0 < KS; ks0 += 4) {      // K is a multiple of 128
+                u32x4 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = *(const u32x4*)(wt + (size_t)(ks0 + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) {
+                        const int m = mf * 16 + l15;
+                        const u32x4 b = *(const u32x4*)(smem_raw + m * RB + ((((ks0 + j) * 4 + g) ^ l15) << 4));
+                        acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lin_bf16x8, a[j]),
+                                                                          __builtin_bit_cast(lin_bf16x8, b), acc[mf], 0, 0, 0);
+                    }
+            }
+            // lane holds columns nt*16 + g*4 + (0..3) of row m0 + mf*16 + l15
+            const int n = nt * 16 + g * 4;
+            const f32x4 bv = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int m = m0 + mf * 16 + l15;
+                f32x4 v = acc[mf] + bv;
+                if (act == ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (m < rows) {
+                    uint2 o;
+                    o.x = lin_pack2(v[0], v[1]);
+                    o.y = lin_pack2(v[2], v[3]);
+                    *(uint2*)(out + ((size_t)m * N + n) * 2) = o;
+                }
+            }
+        }
+    }
+}
+
+int launch_linear_bf16(const float* in, const void* wp, const float* b, void* out, int rows, int K, int N, int act,
+                       hipStream_t s) {
+    LDM_REQUIRE(in && wp && out && rows > 0, "bad arguments");
+    LDM_REQUIRE(K > 0 && K % 128 == 0 && K <= 1024 && N > 0 && N % 16 == 0, "Linear shape not served (K multiple of 128 up to 1024, N multiple of 16)");
+    LDM_REQUIRE(act == ACT_NONE || act == ACT_RELU, "activation not served by the wide Linear");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        LDM_HIP(hipGetDevice(&dev));
+        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const size_t lds = (size_t)64 * K * 2;
+    int grid = N / 64;
+    if (grid > ncu) grid = ncu;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(linear_bf16_kernel, dim3((unsigned)grid), dim3(256), lds, s, in, (const char*)wp, b, (char*)out, rows, K,
+                       N, act);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// ((v + 1) * 127.5) clamped to [0, 255] and truncated, f32 like the reference (an add, then a multiply:
+// nothing to contract).  One thread per pixel.
+__global__ void to_rgb8_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int C, long HW) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* src = in + (size_t)blockIdx.y * C * HW + p;
+    unsigned char* dst = out + ((size_t)blockIdx.y * HW + p) * C;
+    for (int c = 0; c < C; ++c) {
+        float v = (src[(size_t)c * HW] + 1.0f) * 127.5f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);       // NaN -> 0, as Rust's clamp-then-cast gives for `as u8`
+        dst[c] = (unsigned char)(int)v;
+    }
+}
+
+int launch_to_rgb8(const float* in, unsigned char* out, int B, int C, int H, int W, hipStream_t s) {
+    LDM_REQUIRE(in && out && B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "bad arguments");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(to_rgb8_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0, s, in, out, C, HW);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 // emb[r, i] = sin(t_r * f_i), emb[r, half + i] = cos(t_r * f_i), f_i = exp(-(i * 4 ln10 / half))
 __global__ void sin_embed_kernel(const int* __restrict__ t, int rows, int dim, float* __restrict__ out) {
     const int half = dim / 2;

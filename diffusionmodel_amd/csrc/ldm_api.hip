@@ -234,6 +234,10 @@ struct ldm_module {
     AttnP mid_atten, up_atten;
     float *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twt = nullptr, *tbt = nullptr;
     int tv_total = 0;
+    // VAE decoder (kind LDM_MOD_VAE_DECODER): in_ch = latent_dimen, te = image channels
+    PackedConv rev1, rev2, rev3;
+    void* lin_w = nullptr;        // transfer layer: bf16 MFMA fragments (bf16) or f32 [K][N] (f32), columns NHWC-ordered
+    float* lin_b = nullptr;
     // grow-on-demand workspace for the module-level forwards
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -293,10 +297,32 @@ static int pack_conv3x3(ldm_module* m, const std::string& conv, const std::strin
     return pack_conv(sp, m->pool, pc, nullptr);
 }
 
-static int pack_convT(ldm_module* m, const std::string& name, int cin, int cout, PackedConv* pc) {
+// y = (x - mean) / sqrt(var + eps) * gamma + beta after a layer with bias b, as a scale of the layer's weights
+// and a new bias (inference BatchNorm, eps 1e-5); scale 1 / shift b without a BatchNorm
+static int bn_fold(ldm_module* m, const std::string& bn, const std::vector<float>& b, int cout, std::vector<float>* scale,
+                   std::vector<float>* shift) {
+    scale->assign(cout, 1.f);
+    shift->assign(b.begin(), b.begin() + cout);
+    if (bn.empty()) return LDM_OK;
+    const std::vector<float>*g, *be, *mu, *var;
+    LDM_TRY(get_param(m, pjoin(bn, "gamma"), cout, &g));
+    LDM_TRY(get_param(m, pjoin(bn, "beta"), cout, &be));
+    LDM_TRY(get_param(m, pjoin(bn, "running_mean"), cout, &mu));
+    LDM_TRY(get_param(m, pjoin(bn, "running_var"), cout, &var));
+    for (int c = 0; c < cout; ++c) {
+        const double sc = (double)(*g)[c] / std::sqrt((double)(*var)[c] + 1e-5);
+        (*scale)[c] = (float)sc;
+        (*shift)[c] = (float)(((double)b[c] - (double)(*mu)[c]) * sc + (double)(*be)[c]);
+    }
+    return LDM_OK;
+}
+
+static int pack_convT(ldm_module* m, const std::string& name, int cin, int cout, PackedConv* pc, const std::string& bn = "") {
     const std::vector<float>*w, *b;
     LDM_TRY(get_param(m, pjoin(name, "weight"), (size_t)cin * cout * 16, &w));
     LDM_TRY(get_param(m, pjoin(name, "bias"), cout, &b));
+    std::vector<float> scale, shift;
+    LDM_TRY(bn_fold(m, bn, *b, cout, &scale, &shift));
     PackSpec sp;
     sp.kind = CONVT4x4_S2;
     sp.dtype = m->dtype;
@@ -306,7 +332,27 @@ static int pack_convT(ldm_module* m, const std::string& name, int cin, int cout,
     sp.w = [&](int ph, int tap, int co, int ci) {
         const int py = ph >> 1, px = ph & 1, ta = tap >> 1, tb = tap & 1;
         const int ky = 3 - py - 2 * ta, kx = 3 - px - 2 * tb;
-        return (*w)[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+        return (*w)[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx] * scale[co];
+    };
+    sp.bias = [&](int co) { return shift[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+// ConvTranspose2d 3x3, stride 1, padding 1 (weights [cin,cout,3,3]) is a 3x3 convolution with the kernel
+// flipped: out[y,x] = sum in[y + 1 - ky, x + 1 - kx] W[ci][co][ky][kx], i.e. tap (dy,dx) = (2-ky, 2-kx).
+static int pack_convT3x3_s1(ldm_module* m, const std::string& name, int cin, int cout, int cin_padto, PackedConv* pc) {
+    const std::vector<float>*w, *b;
+    LDM_TRY(get_param(m, pjoin(name, "weight"), (size_t)cin * cout * 9, &w));
+    LDM_TRY(get_param(m, pjoin(name, "bias"), cout, &b));
+    PackSpec sp;
+    sp.kind = CONV3x3_S1;
+    sp.dtype = m->dtype;
+    sp.cout = cout;
+    sp.src = {cin};
+    sp.src0_padto = cin_padto;
+    sp.w = [&](int, int tap, int co, int ci) {
+        const int ky = 2 - tap / 3, kx = 2 - tap % 3;
+        return (*w)[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
     };
     sp.bias = [&](int co) { return (*b)[co]; };
     return pack_conv(sp, m->pool, pc, nullptr);
@@ -429,6 +475,40 @@ static int finalize_module(ldm_module* m) {
         LDM_TRY(m->pool.upload((void**)&m->tb1, b1->data(), b1->size() * 4));
         LDM_TRY(m->pool.upload((void**)&m->tw2, w2->data(), w2->size() * 4));
         LDM_TRY(m->pool.upload((void**)&m->tb2, b2->data(), b2->size() * 4));
+    } else if (m->kind == LDM_MOD_VAE_DECODER) {
+        // SimpleDecoder::new, src/main.rs:108-147.  The transfer layer's output [B, 128*16*16] is reshaped to
+        // NCHW [B,128,16,16] (:157): column c*256 + y*16 + x.  Its columns are re-ordered here to
+        // (y*16 + x)*128 + c so that the Linear writes the NHWC tensor the transposed convs read.
+        const int K = m->in_ch * 16, N = 128 * 16 * 16;
+        const std::vector<float>*w, *b;
+        LDM_TRY(get_param(m, "transfer.weight", (size_t)K * N, &w));
+        LDM_TRY(get_param(m, "transfer.bias", N, &b));
+        auto col = [](int n) { return (n & 127) * 256 + (n >> 7); };   // NHWC-ordered column -> reference column
+        std::vector<float> bp(N);
+        for (int n = 0; n < N; ++n) bp[n] = (*b)[col(n)];
+        LDM_TRY(m->pool.upload((void**)&m->lin_b, bp.data(), bp.size() * 4));
+        if (m->dtype == LDM_BF16) {
+            LDM_REQUIRE(K % 128 == 0 && K <= 1024, "latent_dimen must be a multiple of 8 up to 64 for the bf16 decoder");
+            const int KS = K / 32;
+            std::vector<bf16_t> wp((size_t)K * N);
+            for (int nt = 0; nt < N / 16; ++nt)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = nt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+                        const int cn = col(n);
+                        bf16_t* dst = &wp[(((size_t)nt * KS + ks) * 64 + lane) * 8];
+                        for (int e = 0; e < 8; ++e) dst[e] = host_f2bf((*w)[(size_t)(k0 + e) * N + cn]);
+                    }
+            LDM_TRY(m->pool.upload(&m->lin_w, wp.data(), wp.size() * 2));
+        } else {
+            std::vector<float> wp((size_t)K * N);
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < N; ++n) wp[(size_t)k * N + n] = (*w)[(size_t)k * N + col(n)];
+            LDM_TRY(m->pool.upload(&m->lin_w, wp.data(), wp.size() * 4));
+        }
+        LDM_TRY(pack_convT(m, "reverse1", 128, 64, &m->rev1, "bn_1"));
+        LDM_TRY(pack_convT(m, "reverse2", 64, 32, &m->rev2, "bn_2"));
+        LDM_TRY(pack_convT3x3_s1(m, "reverse3", 32, m->te, 64, &m->rev3));
     } else if (m->kind == LDM_MOD_ATTENTION) {
         LDM_TRY(pack_attention(m, "", m->in_ch, &m->mid_atten));
     } else if (m->kind == LDM_MOD_RESBLOCK) {
@@ -750,7 +830,7 @@ int ldm_sin_time_addition(const int* time_dev, int batch, int dim, float* out_de
 int ldm_module_create(ldm_module** out, int kind, int dtype, int in_channels, int time_embed_dim, const int* channels3,
                       int scaled_attention) {
     LDM_REQUIRE(out, "null output");
-    LDM_REQUIRE(kind >= LDM_MOD_UNET && kind <= LDM_MOD_TIME_ADDITION, "unknown module kind");
+    LDM_REQUIRE(kind >= LDM_MOD_UNET && kind <= LDM_MOD_TIME_ADDITION, "unknown module kind (the VAE decoder has its own constructor)");
     LDM_REQUIRE(dtype == LDM_F32 || dtype == LDM_BF16, "unknown dtype");
     LDM_REQUIRE(in_channels > 0, "channels must be positive");
     if (kind == LDM_MOD_UNET || kind == LDM_MOD_RESBLOCK)
@@ -843,6 +923,47 @@ int ldm_time_addition_forward(ldm_module* m, const float* t, float* out, int B, 
     LDM_TRY(launch_linear_f32(t, m->tw1, m->tb1, (float*)m->ws, B, d, d * 8, ACT_RELU, st));
     LDM_TRY(launch_linear_f32((const float*)m->ws, m->tw2, m->tb2, out, B, d * 8, d, ACT_NONE, st));
     return LDM_OK;
+}
+
+int ldm_vae_decoder_create(ldm_module** out, int dtype, int output_channels, int latent_dimen) {
+    LDM_REQUIRE(out, "null output");
+    LDM_REQUIRE(dtype == LDM_F32 || dtype == LDM_BF16, "unknown dtype");
+    LDM_REQUIRE(output_channels > 0 && output_channels <= 64, "image channels must be between 1 and 64");
+    LDM_REQUIRE(latent_dimen > 0 && latent_dimen % 8 == 0 && latent_dimen <= 64, "latent_dimen must be a multiple of 8 up to 64");
+    int ndev = 0;
+    LDM_HIP(hipGetDeviceCount(&ndev));
+    LDM_REQUIRE(ndev > 0, "no HIP device");
+    std::unique_ptr<ldm_module> m(new ldm_module());
+    m->kind = LDM_MOD_VAE_DECODER; m->dtype = dtype; m->in_ch = latent_dimen; m->te = output_channels;
+    *out = m.release();
+    return LDM_OK;
+}
+
+// SimpleDecoder::forward, src/main.rs:149-169 (Dropout is the identity at inference)
+int ldm_vae_decode(ldm_module* m, const float* z, float* img, int B, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_VAE_DECODER && m->finalized, "needs a finalized VAE decoder module");
+    LDM_REQUIRE(z && img && B > 0 && B <= 65535, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = es_of(m->dtype);
+    const int K = m->in_ch * 16, N = 128 * 16 * 16;
+    const size_t y0b = align_up((size_t)B * N * es, 256);                 // [B,16,16,128]
+    const size_t y1b = align_up((size_t)B * 32 * 32 * 64 * es, 256);     // [B,32,32,64]
+    const size_t y2b = align_up((size_t)B * 64 * 64 * 64 * es, 256);     // [B,64,64,64], channels >= 32 zero
+    const size_t y3b = align_up((size_t)B * 64 * 64 * 64 * 4, 256);      // [B,64,64,64] f32, channels >= image channels zero
+    LDM_TRY(ensure_ws(m, y0b + y1b + y2b + y3b));
+    char* base = (char*)m->ws;
+    void *y0 = base, *y1 = base + y0b, *y2 = base + y0b + y1b, *y3 = base + y0b + y1b + y2b;
+    if (m->dtype == LDM_BF16) LDM_TRY(launch_linear_bf16(z, m->lin_w, m->lin_b, y0, B, K, N, ACT_RELU, st));
+    else LDM_TRY(launch_linear_f32(z, (const float*)m->lin_w, m->lin_b, (float*)y0, B, K, N, ACT_RELU, st));
+    LDM_TRY(run_conv(m->rev1, y0, 128, nullptr, 0, y1, B, 16, 16, ACT_RELU, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_conv(m->rev2, y1, 64, nullptr, 0, y2, B, 32, 32, ACT_RELU, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(run_conv(m->rev3, y2, 64, nullptr, 0, y3, B, 64, 64, ACT_TANH, nullptr, nullptr, 0, 1, st));
+    LDM_TRY(launch_nhwc_to_nchw(y3, LDM_F32, img, B, m->te, m->rev3.cout, 64, 64, st));
+    return LDM_OK;
+}
+
+int ldm_to_rgb8(const float* img, unsigned char* out, int B, int C, int H, int W, void* stream) {
+    return launch_to_rgb8(img, out, B, C, H, W, (hipStream_t)stream);
 }
 
 int ldm_conv_create(ldm_conv** out, int kind, int dtype, int cin0, int cin1, int cout, const float* w, const float* b) {

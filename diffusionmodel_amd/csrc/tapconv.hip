@@ -548,6 +548,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         } else if (a.act == ACT_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+        } else if (a.act == ACT_TANH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
         }
         v0 += t0;
         v1 += t1;

@@ -15,8 +15,8 @@ import numpy as np
 import torch
 
 from . import _lib, schedule
-from .weights import (LDMConfig, attention_param_shapes, make_synthetic_weights, resblock_param_shapes,
-                      synthetic_from_shapes, time_addition_param_shapes, unet_param_shapes)
+from .weights import (LDMConfig, attention_param_shapes, decoder_param_shapes, make_synthetic_weights,
+                      resblock_param_shapes, synthetic_from_shapes, time_addition_param_shapes, unet_param_shapes)
 
 _DTYPES = {"bf16": _lib.LDM_BF16, "bfloat16": _lib.LDM_BF16, "fp32": _lib.LDM_F32, "float32": _lib.LDM_F32,
            "f32": _lib.LDM_F32}
@@ -58,9 +58,13 @@ class _Module:
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.dtype = _dtype_code(dtype)
-        ch = (C.c_int * 3)(*channels) if channels is not None else None
-        _lib.check(self._lib.ldm_module_create(C.byref(self._h), kind, self.dtype, int(in_channels),
-                                               int(time_embed_dim), ch, int(bool(scaled_attention))))
+        if kind == _lib.LDM_MOD_VAE_DECODER:     # in_channels = latent_dimen, time_embed_dim = image channels
+            _lib.check(self._lib.ldm_vae_decoder_create(C.byref(self._h), self.dtype, int(time_embed_dim),
+                                                        int(in_channels)))
+        else:
+            ch = (C.c_int * 3)(*channels) if channels is not None else None
+            _lib.check(self._lib.ldm_module_create(C.byref(self._h), kind, self.dtype, int(in_channels),
+                                                   int(time_embed_dim), ch, int(bool(scaled_attention))))
         if weights is None:
             weights = synthetic_from_shapes(shapes, seed)
         self.param_shapes = shapes
@@ -180,6 +184,40 @@ class UNet(_Module):
 Unet = UNet
 
 
+class Decoder(_Module):
+    """SimpleDecoder::new(output, latent_dimen) / forward (LDM.py:86-150 `Decoder`, src/main.rs:96-170):
+    Linear(16 latent_dimen -> 128*16*16) + ReLU, two ConvTranspose 4x4/s2 + BatchNorm + ReLU, a
+    ConvTranspose 3x3/s1 and tanh.  z [B, latent_dimen, 4, 4] -> image [B, output, 64, 64] in [-1, 1].
+    Inference semantics (running statistics, no dropout)."""
+
+    def __init__(self, output: int = 3, latent_dimen: int = 64, dtype="bf16", weights=None, seed: int = 0):
+        self.output, self.latent_dimen = output, latent_dimen
+        super().__init__(_lib.LDM_MOD_VAE_DECODER, dtype, latent_dimen, output,
+                         decoder_param_shapes(output, latent_dimen), weights, seed)
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        z = _dev_f32(z, "z")
+        if z.dim() != 4 or tuple(z.shape[1:]) != (self.latent_dimen, 4, 4):
+            raise ValueError(f"z must be [B, {self.latent_dimen}, 4, 4]")
+        out = torch.empty((z.shape[0], self.output, 64, 64), dtype=torch.float32, device=z.device)
+        _lib.check(self._lib.ldm_vae_decode(self._h, _ptr(z), _ptr(out), z.shape[0], _stream()))
+        return out
+
+    decode = forward
+
+
+def to_rgb8(img: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] float32 in [-1,1] -> [B,H,W,C] uint8 with the arithmetic of save_as_image
+    (src/main.rs:1297-1308): clamp((v + 1) * 127.5, 0, 255) truncated."""
+    img = _dev_f32(img, "img")
+    if img.dim() != 4:
+        raise ValueError("img must be [B, C, H, W]")
+    B, Cc, H, W = img.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.load().ldm_to_rgb8(_ptr(img), _ptr(out), B, Cc, H, W, _stream()))
+    return out
+
+
 def sched_step(z: torch.Tensor, eps: torch.Tensor, coef5, mode: str = "ddpm", last: bool = False,
                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One reverse-process update of `z` in place (src/main.rs:712-756,765); returns z."""
@@ -205,17 +243,20 @@ def philox_normal(batch: int, channels: int, H: int, W: int, seed: int, chain0: 
 
 
 class DiffusionModel:
-    """DiffusionModel::new(latent_dimen, in_channels, num_time, time_embed_dim) (src/main.rs:538-551),
-    UNet side only: the VAE stays with the reference, so `denoising_process` returns the final latent
-    (what the reference hands to vae.decode at :786) instead of decoded pixels."""
+    """DiffusionModel::new(latent_dimen, in_channels, num_time, time_embed_dim) (src/main.rs:538-551).
+    `denoising_process` returns the final latent (what the reference hands to vae.decode at :786);
+    with `decoder_weights` given, `decode` / `sample_images` add the reference's last step (Vae::decode,
+    :786) for 4x4 latents.  The VAE encoder stays with the reference."""
 
     def __init__(self, latent_dimen: int = 64, in_channels: int = 3, num_time: int = 50, time_embed_dim: int = 256,
                  channels: Sequence[int] = (64, 128, 256), scaled_attention: bool = False, dtype="bf16",
-                 weights=None, seed: int = 0, device="cuda"):
+                 weights=None, seed: int = 0, device="cuda", decoder_weights=None):
         self.latent_dimen, self.in_channels = latent_dimen, in_channels
         self.num_time, self.time_embed_dim = num_time, time_embed_dim
         self.device = torch.device(device)
         self.unet = UNet(latent_dimen, time_embed_dim, channels, scaled_attention, dtype, weights, seed)
+        self.decoder = (Decoder(in_channels, latent_dimen, dtype, decoder_weights)
+                        if decoder_weights is not None else None)
         self._lib = _lib.load()
         self._samplers: Dict[Tuple[int, int, int], C.c_void_p] = {}
 
@@ -247,6 +288,18 @@ class DiffusionModel:
     # -- network --------------------------------------------------------------------------------
     def noise_predict(self, x_t: torch.Tensor, time_emb: torch.Tensor) -> torch.Tensor:
         return self.unet.forward(x_t, time_emb)
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """vae.decode(z) (src/main.rs:786): [B, latent_dimen, 4, 4] -> [B, in_channels, 64, 64]."""
+        if self.decoder is None:
+            raise RuntimeError("this DiffusionModel was built without decoder_weights")
+        return self.decoder.forward(z)
+
+    def sample_images(self, batch_size: int, **kw) -> torch.Tensor:
+        """denoising_process followed by vae.decode, as the reference's denoising_process returns
+        (src/main.rs:681-795): [B, in_channels, 64, 64] in [-1, 1]."""
+        kw.pop("return_trace", None)
+        return self.decode(self.denoising_process(batch_size, spatial=4, **kw))
 
     # -- sampling -------------------------------------------------------------------------------
     def _sampler(self, B: int, H: int, W: int) -> C.c_void_p:

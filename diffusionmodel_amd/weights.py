@@ -96,6 +96,22 @@ def unet_param_shapes(cfg: LDMConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return out
 
 
+def decoder_param_shapes(output: int = 3, latent_dimen: int = 64) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Parameters of SimpleDecoder (src/main.rs:96-147) by Rust field path; ConvTranspose2d weights are
+    [Cin,Cout,kh,kw], the Linear's [d_in,d_out]."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    out["transfer.weight"] = (latent_dimen * 16, 128 * 16 * 16)
+    out["transfer.bias"] = (128 * 16 * 16,)
+    out["reverse1.weight"] = (128, 64, 4, 4); out["reverse1.bias"] = (64,)
+    for s in ("gamma", "beta", "running_mean", "running_var"):
+        out[f"bn_1.{s}"] = (64,)
+    out["reverse2.weight"] = (64, 32, 4, 4); out["reverse2.bias"] = (32,)
+    for s in ("gamma", "beta", "running_mean", "running_var"):
+        out[f"bn_2.{s}"] = (32,)
+    out["reverse3.weight"] = (32, output, 3, 3); out["reverse3.bias"] = (output,)
+    return out
+
+
 def synthetic_from_shapes(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     """Seeded f32 CPU tensors for the given name -> shape map (see the module docstring)."""
     g = torch.Generator().manual_seed(seed)
@@ -112,6 +128,8 @@ def synthetic_from_shapes(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 0) -
                 # Ci * 4 products per output pixel
                 is_convT = shape[2] == 4
                 fan_in = shape[0] * 4 if is_convT else shape[1] * shape[2] * shape[3]
+                if name.rsplit(".", 2)[-2] == "reverse3":      # ConvTranspose2d [Ci,Co,3,3] at stride 1
+                    fan_in = shape[0] * 9
             else:
                 fan_in = shape[0]
             out[name] = uni(shape, math.sqrt(3.0 / fan_in))

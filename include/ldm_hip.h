@@ -26,7 +26,7 @@ extern "C" {
 enum { LDM_OK = 0, LDM_ERR_INVALID = 1, LDM_ERR_HIP = 2, LDM_ERR_STATE = 3 };
 enum { LDM_F32 = 0, LDM_BF16 = 1 };                 /* arithmetic type of weights and activations */
 enum { LDM_DDPM = 0, LDM_DDIM = 1 };
-enum { LDM_MOD_UNET = 0, LDM_MOD_RESBLOCK = 1, LDM_MOD_ATTENTION = 2, LDM_MOD_TIME_ADDITION = 3 };
+enum { LDM_MOD_UNET = 0, LDM_MOD_RESBLOCK = 1, LDM_MOD_ATTENTION = 2, LDM_MOD_TIME_ADDITION = 3, LDM_MOD_VAE_DECODER = 4 };
 
 typedef struct ldm_module ldm_module;
 typedef struct ldm_sampler ldm_sampler;
@@ -80,6 +80,22 @@ int ldm_resblock_forward(ldm_module* m, const float* x_dev, const float* t_emb_d
 int ldm_attention_forward(ldm_module* m, const float* x_dev, float* out_dev, int B, int H, int W, void* stream);
 /* TimeAddition::forward(t), src/main.rs:302-306.  t/out [B,dim]. */
 int ldm_time_addition_forward(ldm_module* m, const float* t_dev, float* out_dev, int B, void* stream);
+
+/* ---- the step after the loop: Vae::decode and the 8-bit image ------------------------------- */
+/* SimpleDecoder::new(output, latent_dimen), src/main.rs:108-147.  The module takes its parameters through
+ * ldm_module_set_param / ldm_module_finalize / ldm_module_destroy like the others: "transfer.weight"
+ * [latent_dimen*16, 32768], "transfer.bias", "reverse1.weight" [128,64,4,4], "reverse1.bias", "bn_1.gamma" /
+ * "beta" / "running_mean" / "running_var" [64], "reverse2.weight" [64,32,4,4], "reverse2.bias", "bn_2.*" [32],
+ * "reverse3.weight" [32,output,3,3], "reverse3.bias".  latent_dimen a multiple of 8 up to 64. */
+int ldm_vae_decoder_create(ldm_module** out, int dtype, int output_channels, int latent_dimen);
+/* SimpleDecoder::forward (= Vae::decode, :208-210), src/main.rs:149-169: Linear + ReLU, reshape to
+ * [B,128,16,16], ConvTranspose 4x4/s2 + BatchNorm + ReLU twice, ConvTranspose 3x3/s1, tanh.  Inference
+ * semantics (running statistics, no dropout).  z [B,latent_dimen,4,4], img [B,output_channels,64,64]. */
+int ldm_vae_decode(ldm_module* decoder, const float* z_dev, float* img_dev, int B, void* stream);
+/* The pixel arithmetic of save_as_image, src/main.rs:1297-1308, for every image of the batch:
+ * out[b,y,x,c] = (u8) clamp((img[b,c,y,x] + 1) * 127.5, 0, 255) (f32, truncating; NaN gives 0).
+ * img [B,C,H,W] f32, out [B,H,W,C] u8.  (The reference writes image 0 to a PNG file; files are the caller's.) */
+int ldm_to_rgb8(const float* img_dev, unsigned char* out_dev, int B, int C, int H, int W, void* stream);
 
 /* ---- one convolution on NHWC tensors in the library's own layout (kernel-level operator) --- */
 /* The burn layers behind it: Conv2d 3x3 stride 1 / stride 2 padding 1 (src/main.rs:348-366,423-452,

@@ -123,6 +123,31 @@ def attention(p, prefix: str, x):
 
 
 # --------------------------------------------------------------------------------------------
+# SimpleDecoder::forward (= Vae::decode)                              src/main.rs:149-169, 208-210
+# --------------------------------------------------------------------------------------------
+def vae_decode(p, prefix: str, z):
+    """z [B, latent_dimen, 4, 4] -> [B, output, 64, 64] in [-1, 1].  Dropout (:154) is the identity (D3),
+    BatchNorm uses running statistics (D3/D4)."""
+    pre = prefix + "." if prefix else ""
+    y = z.flatten(1, 3)                                   # :150
+    y = F.relu(linear(p, pre + "transfer", y))            # :151-152
+    y = y.reshape(y.shape[0], 128, 16, 16)                # :156-157
+    y = F.relu(batch_norm(p, pre + "bn_1", conv_transpose2d(p, pre + "reverse1", y, 2, 1)))   # :159-161
+    y = F.relu(batch_norm(p, pre + "bn_2", conv_transpose2d(p, pre + "reverse2", y, 2, 1)))   # :163-165
+    y = conv_transpose2d(p, pre + "reverse3", y, 1, 1)    # :167
+    return torch.tanh(y)                                  # :168
+
+
+def to_rgb8(img) -> np.ndarray:
+    """save_as_image's pixel arithmetic (src/main.rs:1297-1308) for every image: [B,C,H,W] f32 ->
+    [B,H,W,C] u8, ((v + 1.0) * 127.5).clamp(0, 255) as u8 in f32 (Rust's `as u8` truncates; NaN -> 0)."""
+    v = np.asarray(img, dtype=np.float32)
+    v = (v + np.float32(1.0)) * np.float32(127.5)
+    v = np.where(np.isnan(v), np.float32(0.0), np.clip(v, np.float32(0.0), np.float32(255.0)))
+    return np.ascontiguousarray(v.astype(np.uint8).transpose(0, 2, 3, 1))
+
+
+# --------------------------------------------------------------------------------------------
 # Unet::forward                                                      src/main.rs:496-526 (+D1, D7)
 # --------------------------------------------------------------------------------------------
 def unet_forward(p, x, time, scaled_attention: bool = False, return_time_embed: bool = False):

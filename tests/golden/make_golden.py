@@ -18,8 +18,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from diffusionmodel_amd.weights import (LDMConfig, attention_param_shapes, make_synthetic_weights,  # noqa: E402
-                                        resblock_param_shapes, synthetic_from_shapes)
+from diffusionmodel_amd.weights import (LDMConfig, attention_param_shapes, decoder_param_shapes,  # noqa: E402
+                                        make_synthetic_weights, resblock_param_shapes, synthetic_from_shapes)
 from oracle import ldm_oracle as O  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -69,6 +69,11 @@ def main():
     z, zs, eps = O.denoising_process(w, z0, 1000, mode="ddim", ddim_steps=50, trace=True)
     ch.update(ddim_final=z.numpy(), ddim_eps0=eps[0].numpy(), ddim_z10=zs[10].numpy())
     np.savez(os.path.join(OUT, "chains.npz"), **ch)
+    # VAE decoder and the 8-bit image (decoder weights: seed 21)
+    wd = synthetic_from_shapes(decoder_param_shapes(3, 64), 21)
+    zd = randn((2, 64, 4, 4), 55)
+    img = O.vae_decode(wd, "", zd)
+    np.savez(os.path.join(OUT, "decode.npz"), img=img.numpy(), rgb=O.to_rgb8(img.numpy()))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -155,6 +155,56 @@ def test_attention_running_max_jump(A, O, dtype, spike_at):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+# ---- VAE decoder and the 8-bit image ------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [1, 5, 64, 70])
+def test_vae_decode(A, O, dtype, B):
+    # 70: more rows than one pass of the wide Linear holds (64); 5: a ragged last row group
+    w = A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 21)
+    torch.manual_seed(B)
+    z = torch.randn(B, 64, 4, 4)
+    ref = O.vae_decode(w, "", z)
+    _say(f"vae decode {dtype} B={B}")
+    got = A.Decoder(3, 64, dtype=dtype, weights=w)(z.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e} max_err={max_err(got, ref):.3e}")
+    assert got.shape == (B, 3, 64, 64)
+    assert e < TOL[dtype]
+
+
+def test_to_rgb8_bit_exact(A, O):
+    torch.manual_seed(5)
+    img = torch.tanh(torch.randn(3, 3, 64, 64) * 1.5)
+    img[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 0.5, 2.0, -3.0, float("nan"), 0.99999])
+    _say("to_rgb8")
+    got = A.to_rgb8(img.cuda()).cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == (3, 64, 64, 3)
+    assert np.array_equal(got, O.to_rgb8(img.numpy()))
+    one = A.to_rgb8(torch.zeros(2, 1, 5, 7).cuda()).cpu().numpy()     # other channel counts and sizes
+    assert one.shape == (2, 5, 7, 1) and (one == 127).all()
+
+
+def test_sample_images_end_to_end(A, O):
+    """denoising_process + vae.decode as the reference's denoising_process returns (src/main.rs:681-795),
+    f32, 4x4 latents, injected noise: pixels against the restatement."""
+    cfg = A.LDMConfig()
+    w = A.make_synthetic_weights(cfg, 0)
+    wd = A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 21)
+    T, B = 10, 2
+    g = torch.Generator().manual_seed(77)
+    z0, noise = torch.randn((B, 64, 4, 4), generator=g), torch.randn((T, B, 64, 4, 4), generator=g)
+    ref = O.vae_decode(wd, "", O.denoising_process(w, z0, T, noise=noise))
+    _say("sample_images fp32")
+    m = A.DiffusionModel(64, 3, T, 256, dtype="fp32", weights=w, decoder_weights=wd)
+    img = m.sample_images(B, z0=z0.cuda(), noise=noise.cuda())
+    e = rel_err(img, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < 1e-4
+    d = np.abs(A.to_rgb8(img).cpu().numpy().astype(np.int32) - O.to_rgb8(ref.numpy()).astype(np.int32))
+    assert d.max() <= 1
+
+
 # ---- full UNet forward --------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("Cl,B,S", [(64, 4, 4), (64, 2, 16), (8, 2, 8), (64, 1, 64), (64, 16, 64)])

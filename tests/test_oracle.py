@@ -167,3 +167,31 @@ def test_philox_normal_field():
     again = O.philox_normal_nchw(42, 4, 1, 1, 8, 16, 16)
     assert torch.equal(again[0], n[1])
     assert not torch.equal(O.philox_normal_nchw(42, 3, 2, 1, 8, 16, 16)[0], n[0])
+
+
+def test_vae_decode_against_loops():
+    """SimpleDecoder::forward (src/main.rs:149-169) composed from the independent float64 operators."""
+    from diffusionmodel_amd.weights import decoder_param_shapes, synthetic_from_shapes
+    w = synthetic_from_shapes(decoder_param_shapes(3, 64), 21)
+    z = torch.randn((1, 64, 4, 4), generator=torch.Generator().manual_seed(9))
+    got = O.vae_decode(w, "", z).numpy()
+    f = {k: v.double().numpy() for k, v in w.items()}
+    y = np.maximum(z.double().numpy().reshape(1, -1) @ f["transfer.weight"] + f["transfer.bias"], 0.0)
+    y = y.reshape(1, 128, 16, 16)
+    for i, rev in ((1, "reverse1"), (2, "reverse2")):
+        y = N.conv_transpose2d(y, f[rev + ".weight"], f[rev + ".bias"], 2, 1)
+        y = np.maximum(N.batch_norm(y, f[f"bn_{i}.gamma"], f[f"bn_{i}.beta"], f[f"bn_{i}.running_mean"],
+                                    f[f"bn_{i}.running_var"]), 0.0)
+    y = np.tanh(N.conv_transpose2d(y, f["reverse3.weight"], f["reverse3.bias"], 1, 1))
+    assert y.shape == (1, 3, 64, 64) == got.shape
+    assert np.abs(got - y).max() < 2e-5
+    assert np.abs(y).max() <= 1.0 and np.abs(y).std() > 0.05     # not saturated, not flat
+
+
+def test_to_rgb8_known_answers():
+    """((v + 1.0) * 127.5).clamp(0, 255) as u8, src/main.rs:1304-1306: truncation, saturation, NaN -> 0."""
+    v = np.array([-1.0, 1.0, 0.0, 0.5, 2.0, -3.0, np.nan, 0.99999, -0.9961], dtype=np.float32).reshape(1, 1, 3, 3)
+    got = O.to_rgb8(v).reshape(-1)
+    assert list(got) == [0, 255, 127, 191, 255, 0, 0, 254, 0]
+    img = np.zeros((2, 3, 4, 5), np.float32)
+    assert O.to_rgb8(img).shape == (2, 4, 5, 3)
