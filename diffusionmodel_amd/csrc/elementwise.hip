@@ -385,6 +385,7 @@ __device__ __forceinline__ unsigned int lin_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, lin_bf16x2));
 }
 
+template <int NB>     // weight fragments in flight per wave (K / 32 must be a multiple)
 __global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __restrict__ in, const char* __restrict__ wp,
                                                              const float* __restrict__ bias, char* __restrict__ out,
                                                              int rows, int K, int N, int act) {
@@ -415,12 +416,12 @@ __global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __rest
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             const char* wt = wp + (size_t)nt * KS * 1024 + lane * 16;
-            for (int ks0 = 0; ks0 < KS; ks0 += 4) {      // K is a multiple of 128
-                u32x4 a[4];
+            for (int ks0 = 0; ks0 < KS; ks0 += NB) {
+                u32x4 a[NB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = *(const u32x4*)(wt + (size_t)(ks0 + j) * 1024);
+                for (int j = 0; j < NB; ++j) a[j] = *(const u32x4*)(wt + (size_t)(ks0 + j) * 1024);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NB; ++j)
 #pragma unroll
                     for (int mf = 0; mf < 4; ++mf) {
                         const int m = mf * 16 + l15;
@@ -464,15 +465,17 @@ int launch_linear_bf16(const float* in, const void* wp, const float* b, void* ou
     }
     static bool attr_set = false;
     if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const size_t lds = (size_t)64 * K * 2;
     int grid = N / 64;
     if (grid > ncu) grid = ncu;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(linear_bf16_kernel, dim3((unsigned)grid), dim3(256), lds, s, in, (const char*)wp, b, (char*)out, rows, K,
-                       N, act);
+    // 16 KiB of weights in flight per wave when K allows (the stream from HBM is the whole cost)
+    auto kern = (K / 32) % 16 == 0 ? linear_bf16_kernel<16> : linear_bf16_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, in, (const char*)wp, b, (char*)out, rows, K, N, act);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

@@ -173,6 +173,21 @@ def test_vae_decode(A, O, dtype, B):
     assert e < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_vae_decode_small_latent(A, O, dtype):
+    # latent_dimen 8: K = 128 for the wide Linear (its short weight-fragment batches), one image channel
+    w = A.synthetic_from_shapes(A.decoder_param_shapes(1, 8), 3)
+    torch.manual_seed(1)
+    z = torch.randn(3, 8, 4, 4)
+    ref = O.vae_decode(w, "", z)
+    _say(f"vae decode latent 8 {dtype}")
+    got = A.Decoder(1, 8, dtype=dtype, weights=w)(z.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert got.shape == (3, 1, 64, 64) and e < TOL[dtype]
+
+
 def test_to_rgb8_bit_exact(A, O):
     torch.manual_seed(5)
     img = torch.tanh(torch.randn(3, 3, 64, 64) * 1.5)
