@@ -159,20 +159,30 @@ def main():
                      generator=torch.Generator(device="cuda").manual_seed(1234 + rank))
     n_unet_steps = args.ddim_steps
 
+    pending = []      # all-gathers in flight (multi-GPU): call k's gather overlaps call k+1's chains
+
     def one_call():
         if args.sampler == "ddim":
             z = model.ddim_sample(B, args.ddim_steps, spatial=S, z0=z0, chain0=chain0, use_graph=not args.no_graph)
         else:
             z = model.denoising_process(B, spatial=S, z0=z0, seed=7, chain0=chain0, use_graph=not args.no_graph)
         if world > 1:
-            z = A.gather_latents(z, global_batch)
+            pending.append(A.gather_latents_async(z, global_batch))
+            while len(pending) > 2:           # bound the memory held by gathers in flight
+                pending.pop(0).wait()
+            return pending[-1]
         return z
 
     def fence():
+        # every gather issued so far is complete when this returns: nothing leaves the timed region unfinished
+        gathered = None
+        while pending:
+            gathered = pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+        return gathered
 
     for _ in range(args.warmup):
         out = one_call()
@@ -180,8 +190,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_call()
-    fence()
+    gathered = fence()
     dt = time.perf_counter() - t0
+    if world > 1:
+        out = gathered
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -66,6 +66,9 @@
 #ifndef TAPCONV_RING_L3
 #define TAPCONV_RING_L3 3
 #endif
+#ifndef TAPCONV_S2WS_128
+#define TAPCONV_S2WS_128 1
+#endif
 #ifndef TAPCONV_L3_WM
 #define TAPCONV_L3_WM 4
 #define TAPCONV_L3_WN 2
@@ -1102,21 +1105,28 @@ __global__ __launch_bounds__(512, 1) void upfuse_ws_kernel(const TapConvArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight-stationary stride-2 convolution: conv3x3 / stride 2, 64 -> 128 channels, bf16, bias only (down2 of
-// the UNet).  The generic kernel streams 144 KiB of weights per 64 output pixels here and runs at a sixth
-// of the MFMA peak.  Same scheme as tapconv_ws64_kernel: 4 waves, wave w keeps the weights of output
-// channels 32w .. 32w+31 in 144 registers; tiles of 2 x 16 output pixels (5 x 33 input window,
-// double-buffered, columns de-interleaved into even | odd so that a fragment's 16 pixels are consecutive
-// LDS slots); a fragment (window row, column shift, channel half) is read once and serves both output
-// rows where they share the window row; the previous tile's epilogue, its stores and the next tile's DMA
-// pieces are spread over the 72 MFMAs of the current tile.
+// Weight-stationary stride-2 convolution: conv3x3 / stride 2, bf16, bias only (down2 and down3 of the UNet).
+// The generic kernel streams all weights of its channel block per 64 output pixels here and runs at a sixth
+// of the MFMA peak.  Same scheme as tapconv_ws64_kernel: 4 waves, wave w keeps the weights of NF*16 output
+// channels in 144 registers (NCH = 1 input chunk of 64 channels: 32 output channels per wave, 64 -> 128;
+// NCH = 2: 16 per wave, a workgroup owns a block of 64 output channels, 128 -> 256); tiles of 2 x 16 output
+// pixels (5 x 33 input window per chunk, double-buffered, columns de-interleaved into even | odd so that a
+// fragment's 16 pixels are consecutive LDS slots); a fragment (chunk, window row, column shift, channel
+// half) is read once and serves both output rows where they share the window row; the previous tile's
+// epilogue, its stores and the next tile's DMA pieces are spread over the 72 MFMAs of the current tile.
+// Workgroup -> (block of 64*NF output channels, first tile); a.nblk_n = workgroups (= tile stride) per block.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
+template <int NCH, int NF>
+__global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapConvArgs a) {
     constexpr int TR = 2, HH = 2 * TR + 1, HW = 33, HWE = 17, HP = HH * HW;      // 165 window pixels
     constexpr int NG = (HP + 31) / 32;                                           // 6 groups of 32
-    constexpr int HPLANE = NG * 1024, HALO_BYTES = 4 * HPLANE;
-    constexpr int NF = 2, KS = 18, XD = 4, NFR = HH * 6;                         // 30 fragments per tile
-    static_assert(NG == 6, "six halo pieces per wave and tile");
+    constexpr int HPLANE = NG * 1024, CHUNK_BYTES = 4 * HPLANE, HALO_BYTES = NCH * CHUNK_BYTES;
+    constexpr int KS = NCH * 18, XD = 4, NFR = NCH * HH * 6;                     // 30 fragments per chunk and tile
+    constexpr int NPC = NCH * NG;                                                // DMA pieces per wave and tile
+    constexpr int CIN_BYTES = NCH * 128, CB = 64 * NF;                           // output channels per workgroup
+    static_assert(NG == 6, "six halo pieces per wave, chunk and tile");
+    static_assert(NF == 1 || NF == 2, "one or two output-channel fragments per wave");
+    static_assert(KS * NF * 4 <= 144, "weights of a wave in registers");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1124,17 +1134,20 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
     const int g = lane >> 4, l15 = lane & 15;
     const char* zero = (const char*)g_zero16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
+    const int cb = blockIdx.x / a.nblk_n;
+    int tile = blockIdx.x % a.nblk_n;          // the launcher never starts more workgroups per block than tiles
 
+    // slab (chunk c, tap t) = 4 pair planes of [cout][32 bytes]
     u32x4 wreg[KS][NF];
+    const size_t wplane = (size_t)a.cout * 32, wslab = 4 * wplane;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-            wreg[ks][nf] = *(const u32x4*)(a.w + (ks >> 1) * 16384 + ((ks & 1) * 2 + (g >> 1)) * 4096 +
-                                           ((wave * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
+            wreg[ks][nf] = *(const u32x4*)(a.w + (size_t)(ks >> 1) * wslab + ((ks & 1) * 2 + (g >> 1)) * wplane +
+                                           (size_t)(cb * CB + (wave * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
 
-    // halo DMA: piece q of wave w = (group q, plane w); slot -> window pixel, columns de-interleaved
+    // halo DMA: piece (chunk c, group q) of wave w = plane w of the chunk; slot -> window pixel, columns de-interleaved
     int hyx[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -1153,56 +1166,68 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
         const int trem = tt - img * tiles_per_img;
         hiy0 = (trem / a.tiles_x) * TR * 2 - 1;
         hix0 = (trem % a.tiles_x) * 32 - 1;
-        hbase = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
+        hbase = a.in0 + (size_t)img * a.Hin * a.Win * CIN_BYTES + (lane & 1) * 16 + wave * 32;
     };
-    auto halo_piece = [&](int q, int buf) {
+    auto halo_piece = [&](int p, int buf) {
+        const int c = p / NG, q = p - c * NG;
         const int iy = hiy0 + (hyx[q] >> 8), ix = hix0 + (hyx[q] & 255);
         const bool ok = hlive && hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-        const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * 128 : zero;
-        glds16(src, smem + buf * HALO_BYTES + wave * HPLANE + q * 1024);
+        const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * CIN_BYTES + c * 128 : zero;
+        glds16(src, smem + buf * HALO_BYTES + c * CHUNK_BYTES + wave * HPLANE + q * 1024);
     };
     halo_origin(tile);
 #pragma unroll
-    for (int q = 0; q < NG; ++q) halo_piece(q, 0);
+    for (int p = 0; p < NPC; ++p) halo_piece(p, 0);
 
     const unsigned hlane = (g >> 1) * HPLANE + l15 * 32 + (g & 1) * 16;
-    const int co = wave * 32 + (g & 1) * 16 + (g >> 1) * 8;
-    const size_t erow = (size_t)a.Wout * 128;
-    const f32x4 b0 = *(const f32x4*)(a.bias + co), b1 = *(const f32x4*)(a.bias + co + 4);
+    // channels of a lane after the epilogue: NF = 2: 8 consecutive (two fragments exchanged between lane
+    // halves); NF = 1: the 4 accumulator rows g*4 .. g*4+3
+    const int co = cb * CB + (NF == 2 ? wave * 32 + (g & 1) * 16 + (g >> 1) * 8 : wave * 16 + g * 4);
+    const size_t erow = (size_t)a.Wout * a.cout;
+    const f32x4 b0 = *(const f32x4*)(a.bias + co);
+    const f32x4 b1 = NF == 2 ? *(const f32x4*)(a.bias + co + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 accP[NF][TR];
     size_t eP = 0;
     auto epilogue_row = [&](int j) {
-        f32x4 v0, v1;
+        if constexpr (NF == 2) {
+            f32x4 v0, v1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[1][j][q]), false, false);
-            v0[q] = u2f(sw[0]);
-            v1[q] = u2f(sw[1]);
+            for (int q = 0; q < 4; ++q) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[NF - 1][j][q]), false, false);
+                v0[q] = u2f(sw[0]);
+                v1[q] = u2f(sw[1]);
+            }
+            v0 += b0;
+            v1 += b1;
+            u32x4 o;
+            o[0] = pack2(v0[0], v0[1]);
+            o[1] = pack2(v0[2], v0[3]);
+            o[2] = pack2(v1[0], v1[1]);
+            o[3] = pack2(v1[2], v1[3]);
+            *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
+        } else {
+            const f32x4 v0 = accP[0][j] + b0;
+            uint2 o;
+            o.x = pack2(v0[0], v0[1]);
+            o.y = pack2(v0[2], v0[3]);
+            *(uint2*)(a.out + (eP + j * erow) * 2) = o;
         }
-        v0 += b0;
-        v1 += b1;
-        u32x4 o;
-        o[0] = pack2(v0[0], v0[1]);
-        o[1] = pack2(v0[2], v0[3]);
-        o[2] = pack2(v1[0], v1[1]);
-        o[3] = pack2(v1[2], v1[3]);
-        *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
     };
 
     int buf = 0;
     size_t e0 = 0;
-    // per tile and wave: 6 DMA pieces, then the 2 stores of the previous tile's rows
+    // per tile and wave: NPC DMA pieces, then the 2 stores of the previous tile's rows
     // (the first tile has no previous rows to store: after it nothing is younger than its DMA pieces)
     auto tile_top = [&](bool stores_behind) {
         if (stores_behind) wait_vmcnt<2>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        halo_origin(tile + (int)gridDim.x);
+        halo_origin(tile + a.nblk_n);
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int y0 = (trem / a.tiles_x) * TR, x0 = (trem % a.tiles_x) * 16;
-        e0 = (((size_t)img * a.Hout + y0) * a.Wout + x0 + l15) * 128 + co;
+        e0 = (((size_t)img * a.Hout + y0) * a.Wout + x0 + l15) * a.cout + co;
     };
     auto do_tile = [&](auto epi_tag) {
         constexpr bool EPI = decltype(epi_tag)::value;
@@ -1212,10 +1237,11 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
 #pragma unroll
             for (int r = 0; r < TR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* hp0 = smem + buf * HALO_BYTES + hlane;
-        // fragment f = (window row h, column shift dx, channel half kk), kk fastest
+        // fragment f = (chunk c, window row h, column shift dx, channel half kk), kk fastest
         auto foff = [&](int f) {
-            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
-            return kk * 2 * HPLANE + (h * HW + (dx & 1) * HWE + (dx >> 1)) * 32;
+            const int c = f / 30, fr = f % 30;
+            const int h = fr / 6, dx = (fr % 6) >> 1, kk = fr & 1;
+            return c * CHUNK_BYTES + kk * 2 * HPLANE + (h * HW + (dx & 1) * HWE + (dx >> 1)) * 32;
         };
         u32x4 xf[XD];
 #pragma unroll
@@ -1223,11 +1249,12 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
             if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *(const u32x4*)(hp0 + foff(f + XD - 1));
-            if (f < NG) halo_piece(f, buf ^ 1);
-            if (f == NG) asm volatile("" ::: "memory");
-            if (EPI && f == 14) epilogue_row(0);
-            if (EPI && f == 26) epilogue_row(1);
-            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
+            if (f < NPC) halo_piece(f, buf ^ 1);
+            if (f == NPC) asm volatile("" ::: "memory");
+            if (EPI && f == NFR / 2 - 1) epilogue_row(0);
+            if (EPI && f == NFR - 4) epilogue_row(1);
+            const int c = f / 30, fr = f % 30;
+            const int h = fr / 6, dx = (fr % 6) >> 1, kk = fr & 1;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const int dy = h - 2 * r;
@@ -1235,8 +1262,8 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf)
                     acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wreg[(dy * 3 + dx) * 2 + kk][nf]), __builtin_bit_cast(bf16x8, xf[f % XD]),
-                        acc[nf][r], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, wreg[c * 18 + (dy * 3 + dx) * 2 + kk][nf]),
+                        __builtin_bit_cast(bf16x8, xf[f % XD]), acc[nf][r], 0, 0, 0);
             }
             if (f + XD - 1 < NFR) {
                 if (h == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
@@ -1253,10 +1280,10 @@ __global__ __launch_bounds__(256, 2) void s2ws_kernel(const TapConvArgs a) {
 
     tile_top(false);
     do_tile(BoolC<false>{});
-    tile += gridDim.x;
+    tile += a.nblk_n;
     buf ^= 1;
     bool stores_behind = false;
-    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < a.ntiles; tile += a.nblk_n, buf ^= 1) {
         tile_top(stores_behind);
         do_tile(BoolC<true>{});
         stores_behind = true;
@@ -1499,10 +1526,10 @@ bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
 }
 
 static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
-    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 128 && a.Hin % 4 == 0 &&
-           a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
+    const bool c64 = a.nch0 == 1 && a.cout == 128, c128 = a.nch0 == 2 && a.cout == 256;
+    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || (c128 && TAPCONV_S2WS_128)) && a.nch1 == 0 &&
+           a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
 }
-
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     static int ncu = 0;
     if (ncu == 0) {
@@ -1513,9 +1540,24 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     a.tiles_x = a.Wout / 16;
     a.tiles_y = a.Hout / 2;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
-    const size_t lds = 2 * 6 * 4096;                 // two windows of 5 x 33 pixels
-    const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-    hipLaunchKernelGGL(s2ws_kernel, dim3(grid), dim3(256), lds, stream, a);
+    if (a.nch0 == 1) {
+        const size_t lds = 2 * 6 * 4096;                 // two windows of 5 x 33 pixels
+        a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+        hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            LDM_HIP(hipFuncSetAttribute((const void*)s2ws_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const size_t lds = 2 * 2 * 6 * 4096;             // two windows of two chunks
+        const int ncb = a.cout / 64;                     // one workgroup per CU, the CUs split over the channel blocks
+        int per = ncu / ncb;
+        if (per < 1) per = 1;
+        if (per > a.ntiles) per = a.ntiles;
+        a.nblk_n = per;
+        hipLaunchKernelGGL((s2ws_kernel<2, 1>), dim3(per * ncb), dim3(256), lds, stream, a);
+    }
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

@@ -55,6 +55,39 @@ def gather_latents(local: torch.Tensor, global_batch: int, group=None) -> torch.
     return out.to(dev)
 
 
+class PendingGather:
+    """A latent all-gather in flight.  `wait()` makes the current stream (GPU tensors) or the caller (CPU
+    tensors) wait for it and returns the gathered [global_batch, C, H, W] tensor."""
+
+    def __init__(self, out: torch.Tensor, work, keep):
+        self._out, self._work, self._keep = out, work, keep
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        return self._out
+
+
+def gather_latents_async(local: torch.Tensor, global_batch: int, group=None) -> PendingGather:
+    """gather_latents that returns at once: the collective runs on the backend's own stream while the caller
+    launches the next chains (RCCL: ordered after the work already queued on the current stream).  Ranks
+    must hold equally many chains and, with `gloo`, CPU tensors; any other case is done synchronously."""
+    if not dist.is_available() or not dist.is_initialized():
+        return PendingGather(gather_latents(local, global_batch, group), None, None)
+    world = dist.get_world_size(group)
+    sizes = {chain_range(global_batch, r, world)[1] - chain_range(global_batch, r, world)[0] for r in range(world)}
+    if len(sizes) != 1 or (dist.get_backend(group) == "gloo" and local.is_cuda):
+        return PendingGather(gather_latents(local, global_batch, group), None, None)
+    if local.shape[0] * world != global_batch:
+        raise ValueError(f"this rank holds {local.shape[0]} chains, expected {global_batch // world}")
+    src = local.contiguous()
+    out = torch.empty((global_batch,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    work = dist.all_gather_into_tensor(out, src, group=group, async_op=True)
+    return PendingGather(out, work, src)
+
+
 def sample_sharded(sample_fn: Callable[[int, int], torch.Tensor], global_batch: int, group=None,
                    rank: Optional[int] = None, world_size: Optional[int] = None) -> torch.Tensor:
     """Runs `sample_fn(local_batch, chain0)` on this rank's slice and gathers all slices.

@@ -155,6 +155,27 @@ def test_attention_running_max_jump(A, O, dtype, spike_at):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+# ---- stride-2 convolutions at the sizes of the weight-stationary kernels --------------------------
+@pytest.mark.parametrize("B,S,cin,cout", [(16, 64, 64, 128), (64, 32, 128, 256), (70, 32, 128, 256), (3, 32, 128, 256)])
+def test_conv_stride2_large(A, B, S, cin, cout):
+    """conv3x3 / stride 2 (down2, down3; src/main.rs:434-452) through the kernel-level operator at batch
+    sizes that reach the weight-stationary kernels (and one that does not), against torch on the same
+    bf16-rounded operands."""
+    import torch.nn.functional as F
+    from diffusionmodel_amd.ops import ConvOp, from_nhwc, to_nhwc
+    g = torch.Generator().manual_seed(B + cin)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * cin ** 0.5))).bfloat16().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, S, S, generator=g).bfloat16().float()
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    _say(f"conv3x3_s2 B={B} S={S} {cin}->{cout}")
+    got = from_nhwc(ConvOp("conv3x3_s2", w, b, dtype="bf16")(to_nhwc(x, "bf16").cuda()))
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < 4e-3      # bf16 rounding of the output only
+
+
 # ---- VAE decoder and the 8-bit image ------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [1, 5, 64, 70])

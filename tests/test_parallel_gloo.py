@@ -34,6 +34,16 @@ def _worker(rank, world, port, global_batch, q):
         got = sample_sharded(_fake_sample, global_batch)
         first, last = chain_range(global_batch, rank, world)
         q.put((rank, got, (first, last)))
+        # the same gather left in flight while the next batch is produced (what bench.py does between calls)
+        from diffusionmodel_amd import gather_latents_async
+        pend = [gather_latents_async(_fake_sample(last - first, first + 100 * k), global_batch) for k in range(3)]
+        for k, pg in enumerate(pend):
+            full = pg.wait()
+            if global_batch % world == 0:
+                assert torch.equal(full, torch.cat([_fake_sample(global_batch // world, r * (global_batch // world) + 100 * k)
+                                                    for r in range(world)]))
+            else:
+                assert full.shape[0] == global_batch
         dist.barrier()
     finally:
         dist.destroy_process_group()
