@@ -278,3 +278,31 @@ def test_unet_scaled(A, O, dtype):
     e = rel_err(got, ref)
     _say(f"  rel_err={e:.3e}")
     assert e < TOL[dtype]
+
+
+# ---- full benchmark size: properties that need no CPU reference ------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_unet_full_size_batch_slices_agree(A, dtype):
+    """[64,64,64,64] (the benchmark's per-GPU batch): chains are independent, so the noise predicted for the
+    whole batch equals the noise predicted for its four slices of 16 (which take other kernels and tilings:
+    the summation order inside a dot product may differ, nothing else), and every slice was checked against
+    the restatement at this size in test_unet_forward."""
+    cfg = A.LDMConfig()
+    net = A.UNet(64, 256, dtype=dtype, weights=A.make_synthetic_weights(cfg, 0))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(64, 64, 64, 64, generator=g).cuda()
+    t = torch.randint(0, 1000, (64,), generator=g)
+    te = A.sin_time_addition(t.cuda(), 256)
+    _say(f"unet full size {dtype}")
+    whole = net(x, te)
+    parts = torch.cat([net(x[i:i + 16].contiguous(), te[i:i + 16].contiguous()) for i in range(0, 64, 16)])
+    torch.cuda.synchronize()
+    e = rel_err(whole, parts)
+    _say(f"  whole batch vs slices: rel_err={e:.3e}")
+    assert torch.isfinite(whole).all()
+    assert e < (1e-5 if dtype == "fp32" else 1e-2)
+    # permuting the chains permutes the result
+    perm = torch.randperm(64, generator=g).cuda()
+    again = net(x[perm].contiguous(), te[perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(again, whole[perm])
