@@ -311,7 +311,8 @@ template <int D, int QF, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
                                                                   int N, float scale_log2e) {
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
-    constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4;
+    // ring depth: four stages where they fit (C = 256), else two (C = 512: a stage is 64 KiB)
+    constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4 * 2 * TILE <= 160 * 1024 ? 4 : 2;
     constexpr int QB = NW * QF * 16, PPT = NPIECE / NW, PPW = 2 * PPT;
     static_assert(NPIECE % NW == 0, "every wave issues the same number of pieces");
     static_assert(NST * 2 * TILE <= 160 * 1024, "LDS budget");
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         }
     };
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
+    for (int t = 0; t < (NST >= 3 ? NST - 1 : 1); ++t)
         if (t < ntiles) issue_tile(t);
 
     u32x4 qreg[QF][KS];
@@ -492,11 +493,24 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     at_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    for (int t = 0; t < ntiles; ++t) {
-        s_phase(t);
-        softmax();
-        pv_phase(t);
-        tail(t);
+    if constexpr (NST >= 3) {
+        for (int t = 0; t < ntiles; ++t) {
+            s_phase(t);
+            softmax();
+            pv_phase(t);
+            tail(t);
+        }
+    } else {
+        // two stages: tile t+1 goes into the stage that barrier t-1 freed, at the START of interval t, and has the
+        // whole interval to land
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) issue_tile(t + 1);
+            s_phase(t);
+            softmax();
+            pv_phase(t);
+            at_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
@@ -521,7 +535,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 template <int D, int QF, int NW>
 static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream) {
     constexpr int QB = NW * QF * 16;
-    constexpr size_t lds = (size_t)4 * 2 * 32 * D * 2;
+    constexpr size_t stage = (size_t)2 * 32 * D * 2;
+    constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage;
     auto kern = attention_stream_kernel<D, QF, NW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -569,7 +584,9 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
 #endif
                 if ((long)B * ((N + 127) / 128) < 256) return launch_attn_cfg<bf16_t, 256, 1, 2, 2>(qkv, out, B, N, stream);
                 return launch_attn_cfg<bf16_t, 256, 2, 2>(qkv, out, B, N, stream);
-            case 512: return launch_attn_cfg<bf16_t, 512, 1, 2>(qkv, out, B, N, stream);
+            case 512:
+                if (N % 128 == 0 && N >= 512 && (long)B * (N / 128) >= 256) return launch_attn_stream<512, 1, 8>(qkv, out, B, N, stream);
+                return launch_attn_cfg<bf16_t, 512, 1, 2>(qkv, out, B, N, stream);
         }
     } else {
         switch (C) {

@@ -97,8 +97,9 @@ def test_resblock(A, O, dtype, C, B, H, W):
 # ---- Attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,B,H,W", [(256, 2, 4, 4), (256, 2, 16, 16), (128, 1, 12, 20), (256, 1, 1, 1), (512, 1, 8, 8),
-                                      (256, 64, 16, 16), (256, 64, 32, 32)])
+                                      (256, 64, 16, 16), (256, 64, 32, 32), (512, 64, 16, 32)])
 def test_attention(A, O, dtype, C, B, H, W):
+    # (512, 64, 16, 32): 512 tokens x 256 workgroups of 128 queries: the long-sequence kernel at 512 channels (bf16)
     # (256, 64, 16, 16): enough tokens for the weight-stationary 1x1 kernels of the projections (bf16)
     # (256, 64, 32, 32): 1024 tokens x 256 workgroups of 256 queries: the long-sequence attention kernel (bf16)
     from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
