@@ -38,6 +38,9 @@ SIGNATURES = {
     "ldm_resblock_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_time_addition_forward": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "ldm_add_noise_coefficients": (_i, [_i, _fp]),
+    "ldm_add_noise": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _l, _vp]),
+    "ldm_mse": (_i, [_vp, _vp, _l, _vp, _vp, _vp]),
     "ldm_vae_decoder_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
     "ldm_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
     "ldm_to_rgb8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -132,6 +132,11 @@ int launch_linear_bf16(const float* in, const void* wp, const float* b, void* ou
 // NCHW f32 [B,C,H,W] in [-1,1] -> HWC u8 [B,H,W,C]: ((v + 1) * 127.5) clamped to [0,255], truncated
 // (save_as_image, src/main.rs:1297-1308)
 int launch_to_rgb8(const float* in, unsigned char* out, int B, int C, int H, int W, hipStream_t s);
+// forward process (src/main.rs:584-630): out[b] = x[b] * coef[t_b][0] + noise[b] * coef[t_b][1], coef [num_time][2]
+int launch_add_noise(const float* x, const float* noise, const int* t, const float* coef, int num_time, float* out, int B,
+                     long per_sample, hipStream_t s);
+// out[0] = mean((a - b)^2) over n elements; partial_ws: 1024 floats of device scratch
+int launch_mse(const float* a, const float* b, long n, float* partial_ws, float* out, hipStream_t s);
 // sinusoidal embedding of integer timesteps (src/main.rs:309-335)
 int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s);
 

@@ -113,7 +113,67 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const SchedArgs a) {
         }
     }
 }
+
+// Forward process q(x_t | x_0), DiffusionModel::add_noise (src/main.rs:584-630):
+//   noisy = x * sqrt_alpha[t_b] + noise * sqrt_one_minus_alpha[t_b]
+// as two products and a sum (three tensor operations in the reference: no FMA).  coef = [num_time][2];
+// a timestep outside [0, num_time) takes the last row (`(t as usize).min(len - 1)`, :606).
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                        const int* __restrict__ t, const float* __restrict__ coef, int num_time,
+                                                        float* __restrict__ out, long per_sample4) {
+    const int b = blockIdx.y;
+    int ti = t[b];
+    if (ti < 0 || ti > num_time - 1) ti = num_time - 1;
+    const float sa = coef[2 * ti], s1m = coef[2 * ti + 1];
+    const f32x4* xs = (const f32x4*)x + (size_t)b * per_sample4;
+    const f32x4* ns = (const f32x4*)noise + (size_t)b * per_sample4;
+    f32x4* os = (f32x4*)out + (size_t)b * per_sample4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 xv = xs[i], nv = ns[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float p0 = xv[q] * sa;
+            const float p1 = nv[q] * s1m;
+            o[q] = p0 + p1;
+        }
+        os[i] = o;
+    }
+}
 #pragma clang fp contract(on)
+
+// Mean squared difference (the diffusion loss, src/main.rs:665-671): every workgroup sums a fixed, strided
+// part of the elements in a fixed order (lane partials, then a tree over the workgroup), a second launch adds
+// the workgroup sums in order and divides: the result does not depend on scheduling.
+constexpr int MSE_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)MSE_BLOCKS * 256) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ partial, long n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < MSE_BLOCKS; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
 
 static inline int ew_grid(long work_items) {
     long g = (work_items + 255) / 256;
@@ -498,6 +558,27 @@ int launch_to_rgb8(const float* in, unsigned char* out, int B, int C, int H, int
     LDM_REQUIRE(in && out && B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "bad arguments");
     const long HW = (long)H * W;
     hipLaunchKernelGGL(to_rgb8_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0, s, in, out, C, HW);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+int launch_add_noise(const float* x, const float* noise, const int* t, const float* coef, int num_time, float* out, int B,
+                     long per_sample, hipStream_t s) {
+    LDM_REQUIRE(x && noise && t && coef && out, "null tensor");
+    LDM_REQUIRE(B > 0 && B <= 65535 && num_time > 0 && per_sample > 0 && per_sample % 4 == 0,
+                "batch up to 65535 and a sample size that is a multiple of 4");
+    const long p4 = per_sample / 4;
+    long gx = (p4 + 255) / 256;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, s, x, noise, t, coef, num_time, out, p4);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+int launch_mse(const float* a, const float* b, long n, float* partial_ws, float* out, hipStream_t s) {
+    LDM_REQUIRE(a && b && partial_ws && out && n > 0, "bad arguments");
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, s, a, b, n, partial_ws);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, n, out);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

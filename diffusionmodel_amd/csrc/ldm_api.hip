@@ -94,6 +94,23 @@ static void host_ddpm_coef(int T, std::vector<float>& tab) {   // [T][5]
         }
     }
 }
+// add_noise's per-timestep scalars, src/main.rs:603-624: the gathered alpha-bar is replaced by 1e-6 when it is
+// not a positive finite number and clamped to [1e-8, 0.9999] otherwise; sqrt(alpha) is clamped to [1e-8, 1],
+// 1 - alpha to [1e-8, 1] before its square root.
+static void host_add_noise_coef(int T, std::vector<float>& tab) {   // [T][2]
+    std::vector<float> ab;
+    host_alpha_bars(T, ab);
+    tab.assign((size_t)T * 2, 0.f);
+    for (int i = 0; i < T; ++i) {
+        float a = ab[i];
+        if (std::isnan(a) || std::isinf(a) || a <= 0.0f) a = 1e-6f;
+        else a = std::fmin(std::fmax(a, 1e-8f), 0.9999f);
+        const float sa = std::fmin(std::fmax(sqrtf(a), 1e-8f), 1.0f);
+        const float om = std::fmin(std::fmax(1.0f - a, 1e-8f), 1.0f);
+        tab[2 * i] = sa;
+        tab[2 * i + 1] = sqrtf(om);
+    }
+}
 static int host_ddim_ts(int T, int steps, std::vector<int>& ts) {
     LDM_REQUIRE(steps >= 1 && steps <= T, "ddim steps must be in [1, num_time]");
     const int stride = T / steps;
@@ -821,6 +838,23 @@ int ldm_ddim_coefficients(int num_time, int steps, float* out) {
     LDM_TRY(host_ddim_coef(num_time, steps, t));
     memcpy(out, t.data(), t.size() * 4);
     return LDM_OK;
+}
+
+int ldm_add_noise_coefficients(int num_time, float* out) {
+    LDM_REQUIRE(num_time > 0 && out, "bad arguments");
+    std::vector<float> t;
+    host_add_noise_coef(num_time, t);
+    std::memcpy(out, t.data(), t.size() * 4);
+    return LDM_OK;
+}
+
+int ldm_add_noise(const float* x, const float* noise, const int* t, const float* coef, int num_time, float* out, int B,
+                  long per_sample, void* stream) {
+    return launch_add_noise(x, noise, t, coef, num_time, out, B, per_sample, (hipStream_t)stream);
+}
+
+int ldm_mse(const float* a, const float* b, long n, float* ws1024, float* out, void* stream) {
+    return launch_mse(a, b, n, ws1024, out, (hipStream_t)stream);
 }
 
 int ldm_sin_time_addition(const int* time_dev, int batch, int dim, float* out_dev, void* stream) {

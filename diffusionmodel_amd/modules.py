@@ -289,6 +289,46 @@ class DiffusionModel:
     def noise_predict(self, x_t: torch.Tensor, time_emb: torch.Tensor) -> torch.Tensor:
         return self.unet.forward(x_t, time_emb)
 
+    # -- forward process and loss value (the step before the path in training; no backward here) ----
+    def add_noise(self, x: torch.Tensor, time: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """DiffusionModel::add_noise(x, time) (src/main.rs:584-630): returns (noisy, noise) with
+        noisy = x * sqrt(alpha_bar_t) + noise * sqrt(1 - alpha_bar_t) per sample (the reference's clamps
+        included).  `noise` may be injected; otherwise it is drawn with torch on the device."""
+        x = _dev_f32(x, "x")
+        if x.dim() < 2 or (x.numel() // x.shape[0]) % 4 != 0:
+            raise ValueError("x must be [B, ...] with a sample size that is a multiple of 4")
+        B = x.shape[0]
+        if noise is None:
+            noise = torch.randn_like(x)
+        noise = _dev_f32(noise, "noise", tuple(x.shape))
+        t = time.to(device=x.device, dtype=torch.int32).contiguous()
+        if t.numel() != B:
+            raise ValueError(f"time must hold {B} timesteps")
+        if getattr(self, "_an_coef", None) is None or self._an_coef.device != x.device:
+            self._an_coef = torch.from_numpy(schedule.add_noise_coefficients(self.num_time)).to(x.device)
+        out = torch.empty_like(x)
+        _lib.check(self._lib.ldm_add_noise(_ptr(x), _ptr(noise), _ptr(t), _ptr(self._an_coef), self.num_time, _ptr(out),
+                                           B, x.numel() // B, _stream()))
+        return out, noise
+
+    def forward(self, z: torch.Tensor, time: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The loss value of DiffusionModel::forward (src/main.rs:635-679) from the latent on: random
+        timesteps (or `time`), add_noise, sinusoidal embedding, noise prediction, mean squared error.
+        z is what the reference obtains from vae.encode(x).detach() (:636; the encoder stays with the
+        reference).  Returns a tensor of shape [1].  Value only: there is no backward pass here."""
+        z = _dev_f32(z, "z")
+        B = z.shape[0]
+        if time is None:
+            time = torch.randint(0, self.num_time, (B,), device=z.device)
+        z_noisy, noise = self.add_noise(z, time, noise)
+        t_emb = sin_time_addition(time.to(z.device), self.time_embed_dim)
+        pred = self.noise_predict(z_noisy, t_emb)
+        ws = torch.empty(1024, dtype=torch.float32, device=z.device)
+        out = torch.empty(1, dtype=torch.float32, device=z.device)
+        _lib.check(self._lib.ldm_mse(_ptr(pred), _ptr(noise), pred.numel(), _ptr(ws), _ptr(out), _stream()))
+        return out
+
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         """vae.decode(z) (src/main.rs:786): [B, latent_dimen, 4, 4] -> [B, in_channels, 64, 64]."""
         if self.decoder is None:

@@ -41,3 +41,10 @@ def ddim_coefficients(num_time: int, steps: int) -> np.ndarray:
     out = np.empty((steps, 5), dtype=np.float32)
     _lib.check(_lib.load().ldm_ddim_coefficients(num_time, steps, out.ctypes.data_as(_FP)))
     return out
+
+
+def add_noise_coefficients(num_time: int) -> np.ndarray:
+    """[num_time, 2] = {sqrt_alpha, sqrt_one_minus_alpha} with the clamps of add_noise (src/main.rs:603-624)."""
+    out = np.empty((num_time, 2), dtype=np.float32)
+    _lib.check(_lib.load().ldm_add_noise_coefficients(num_time, out.ctypes.data_as(_FP)))
+    return out

@@ -97,6 +97,21 @@ int ldm_vae_decode(ldm_module* decoder, const float* z_dev, float* img_dev, int 
  * img [B,C,H,W] f32, out [B,H,W,C] u8.  (The reference writes image 0 to a PNG file; files are the caller's.) */
 int ldm_to_rgb8(const float* img_dev, unsigned char* out_dev, int B, int C, int H, int W, void* stream);
 
+/* ---- the step before the path in training: forward process and the loss value (no backward) -- */
+/* The two scalars DiffusionModel::add_noise derives per timestep, src/main.rs:603-624 (alpha-bar made safe
+ * and clamped to [1e-8, 0.9999]; sqrt clamped to [1e-8, 1]; sqrt of 1 - alpha clamped to [1e-8, 1]):
+ * out_host [num_time][2] = {sqrt_alpha, sqrt_one_minus_alpha}. */
+int ldm_add_noise_coefficients(int num_time, float* out_host);
+/* DiffusionModel::add_noise, src/main.rs:584-630, with the noise supplied by the caller:
+ * out[b] = x[b] * coef[t_b][0] + noise[b] * coef[t_b][1] (two products and a sum, f32).  x / noise / out
+ * [B, per_sample] f32 (per_sample a multiple of 4), t_dev int[B] (outside [0, num_time): last row, :606),
+ * coef_dev = the table above in device memory. */
+int ldm_add_noise(const float* x_dev, const float* noise_dev, const int* t_dev, const float* coef_dev, int num_time,
+                  float* out_dev, int B, long per_sample, void* stream);
+/* The loss value of DiffusionModel::forward, src/main.rs:665-671: out_dev[0] = mean((a - b)^2) over n f32
+ * elements, summed in a fixed order.  ws1024_dev: 1024 floats of device scratch. */
+int ldm_mse(const float* a_dev, const float* b_dev, long n, float* ws1024_dev, float* out_dev, void* stream);
+
 /* ---- one convolution on NHWC tensors in the library's own layout (kernel-level operator) --- */
 /* The burn layers behind it: Conv2d 3x3 stride 1 / stride 2 padding 1 (src/main.rs:348-366,423-452,
  * 486-492), ConvTranspose2d 4x4 stride 2 padding 1 (:460-480), Conv2d 1x1 on a channel concatenation

@@ -329,6 +329,45 @@ NOISE_TAG = 0x4C444D31
 INIT_STEP = 0xFFFFFFFF
 
 
+# --------------------------------------------------------------------------------------------
+# forward process and loss value (training side, no backward)         src/main.rs:584-679
+# --------------------------------------------------------------------------------------------
+def add_noise_coefficients(num_time: int) -> np.ndarray:
+    """[num_time, 2] f32 = {sqrt_alpha, sqrt_one_minus_alpha} as add_noise derives them (:603-624)."""
+    ab = get_alphas(num_time)
+    out = np.empty((num_time, 2), dtype=np.float32)
+    for i in range(num_time):
+        a = np.float32(ab[i])
+        if np.isnan(a) or np.isinf(a) or a <= 0.0:
+            a = np.float32(1e-6)                                                  # :609-610
+        else:
+            a = np.float32(min(max(a, np.float32(1e-8)), np.float32(0.9999)))     # :612
+        out[i, 0] = min(max(np.sqrt(a, dtype=np.float32), np.float32(1e-8)), np.float32(1.0))   # :622
+        om = np.float32(1.0) - a                                                  # :623
+        out[i, 1] = np.sqrt(np.float32(min(max(om, np.float32(1e-8)), np.float32(1.0))), dtype=np.float32)   # :624
+    return out
+
+
+def add_noise(x: torch.Tensor, time, num_time: int, noise: torch.Tensor) -> torch.Tensor:
+    """noisy = x * sqrt_alpha + noise * sqrt_one_minus_alpha (:627), the scalars gathered per sample with
+    `(t as usize).min(len - 1)` (:606: a negative i32 becomes a huge usize, i.e. the last entry)."""
+    coef = add_noise_coefficients(num_time)
+    idx = [int(t) if 0 <= int(t) <= num_time - 1 else num_time - 1 for t in time]
+    shape = (len(idx),) + (1,) * (x.dim() - 1)
+    sa = torch.from_numpy(coef[idx, 0]).reshape(shape)
+    s1m = torch.from_numpy(coef[idx, 1]).reshape(shape)
+    return x * sa + noise * s1m
+
+
+def diffusion_loss(p, z: torch.Tensor, time, num_time: int, noise: torch.Tensor, time_embed_dim: int = 256) -> torch.Tensor:
+    """DiffusionModel::forward from the latent on (:641-679): add_noise, sin_time_addition, noise_predict,
+    mean of the squared difference.  The NaN probes (:645-650, 657-662, 673-677) are not reproduced (D5)."""
+    z_noisy = add_noise(z, time, num_time, noise)
+    t_emb = sin_time_addition(torch.as_tensor(list(time)), time_embed_dim)
+    pred = unet_forward(p, z_noisy, t_emb)
+    return ((pred.flatten(1) - noise.flatten(1)) ** 2).mean().reshape(1)
+
+
 def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
     """Philox-4x32-10 (Salmon et al. 2011).  ctr [..., 4] uint32, key [2] uint32 -> [..., 4] uint32."""
     c = ctr.astype(np.uint32).copy()

@@ -177,6 +177,40 @@ def test_conv_stride2_large(A, B, S, cin, cout):
     assert e < 4e-3      # bf16 rounding of the output only
 
 
+# ---- forward process and loss value ---------------------------------------------------------------
+def test_add_noise_bit_exact(A, O):
+    T, B = 1000, 6
+    m = A.DiffusionModel(64, 3, T, 256, dtype="fp32", weights=A.make_synthetic_weights(A.LDMConfig(), 0))
+    g = torch.Generator().manual_seed(4)
+    x, n = torch.randn(B, 64, 4, 4, generator=g), torch.randn(B, 64, 4, 4, generator=g)
+    t = torch.tensor([0, 1, 500, 999, 4000, -2])
+    _say("add_noise")
+    got, n_back = m.add_noise(x.cuda(), t.cuda(), n.cuda())
+    ref = O.add_noise(x, t.tolist(), T, n)
+    assert torch.equal(got.cpu(), ref) and torch.equal(n_back.cpu(), n)
+    noisy, drawn = m.add_noise(x.cuda(), t.cuda())                    # noise drawn on the device
+    assert torch.equal(noisy.cpu(), O.add_noise(x, t.tolist(), T, drawn.cpu()))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_diffusion_loss_value(A, O, dtype):
+    """DiffusionModel::forward from the latent on (src/main.rs:641-679), timesteps and noise injected."""
+    T, B, S = 1000, 4, 8
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    g = torch.Generator().manual_seed(8)
+    z, n = torch.randn(B, 64, S, S, generator=g), torch.randn(B, 64, S, S, generator=g)
+    t = torch.tensor([3, 250, 600, 999])
+    ref = O.diffusion_loss(w, z, t.tolist(), T, n).item()
+    _say(f"diffusion loss {dtype}")
+    m = A.DiffusionModel(64, 3, T, 256, dtype=dtype, weights=w)
+    got = m.forward(z.cuda(), t.cuda(), n.cuda())
+    assert got.shape == (1,)
+    e = abs(got.item() - ref) / abs(ref)
+    _say(f"  loss={got.item():.6f} ref={ref:.6f} rel={e:.3e}")
+    assert e < (1e-5 if dtype == "fp32" else 2e-2)
+    assert m.forward(z.cuda()).item() > 0.0                            # random timesteps and noise
+
+
 # ---- VAE decoder and the 8-bit image ------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [1, 5, 64, 70])

@@ -195,3 +195,24 @@ def test_to_rgb8_known_answers():
     assert list(got) == [0, 255, 127, 191, 255, 0, 0, 254, 0]
     img = np.zeros((2, 3, 4, 5), np.float32)
     assert O.to_rgb8(img).shape == (2, 4, 5, 3)
+
+
+def test_add_noise_coefficients_and_gather():
+    """src/main.rs:603-627: clamps of the gathered alpha-bar and out-of-range timesteps."""
+    T = 1000
+    c = O.add_noise_coefficients(T)
+    ab = O.get_alphas(T).astype(np.float64)
+    assert c.shape == (T, 2) and c.dtype == np.float32
+    assert abs(c[0, 0] - np.sqrt(min(ab[0], 0.9999))) < 1e-6          # alpha-bar_0 = 0.9999 hits the upper clamp
+    assert np.allclose(c[1:, 0], np.sqrt(ab[1:]), atol=1e-6) and np.allclose(c[1:, 1], np.sqrt(1 - ab[1:]), atol=1e-6)
+    assert np.allclose(c[:, 0] ** 2 + c[:, 1] ** 2, 1.0, atol=2e-4)
+    x, n = torch.ones(4, 2, 2, 2), torch.full((4, 2, 2, 2), 2.0)
+    y = O.add_noise(x, [0, 999, 5000, -3], T, n)
+    for b, i in enumerate([0, 999, 999, 999]):
+        assert torch.allclose(y[b], torch.full((2, 2, 2), float(c[i, 0] + 2.0 * c[i, 1])))
+
+
+def test_host_add_noise_coefficients_match_oracle():
+    from diffusionmodel_amd import schedule
+    for T in (50, 1000):
+        assert np.array_equal(schedule.add_noise_coefficients(T), O.add_noise_coefficients(T))
