@@ -341,3 +341,44 @@ def test_unet_full_size_batch_slices_agree(A, dtype):
     again = net(x[perm].contiguous(), te[perm].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(again, whole[perm])
+
+
+# ---- error behaviour: rejected on the host, before any kernel runs ---------------------------------
+def test_invalid_arguments_are_rejected(A):
+    from diffusionmodel_amd import _lib
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    _say("error paths")
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    net = A.UNet(64, 256, dtype="bf16", weights=w)
+    te = torch.zeros(1, 256, device="cuda")
+    with pytest.raises(_lib.LdmError, match="multiples of 4"):
+        net(torch.zeros(1, 64, 6, 8, device="cuda"), te)                   # H not a multiple of 4
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 32, 8, 8, device="cuda"), te)                   # wrong channel count
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 64, 8, 8), te)                                  # host tensor
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 64, 8, 8, device="cuda", dtype=torch.float16), te)
+    bad = dict(w)
+    del bad["mid_res1.conv2.bias"]
+    with pytest.raises(KeyError):
+        A.UNet(64, 256, weights=bad)
+    bad = dict(w)
+    bad["down1.weight"] = torch.zeros(64, 64, 5, 5)
+    with pytest.raises(ValueError):
+        A.UNet(64, 256, weights=bad)
+    with pytest.raises(_lib.LdmError, match="attention supports"):
+        A.Attention(192, weights=synthetic_from_shapes(attention_param_shapes(192), 0))(torch.zeros(1, 192, 4, 4, device="cuda"))
+    with pytest.raises(ValueError):
+        A.Decoder(3, 64, weights=A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 1))(torch.zeros(2, 64, 8, 8, device="cuda"))
+    with pytest.raises(_lib.LdmError):
+        A.Decoder(3, 12)                                                   # latent_dimen must be a multiple of 8
+    m = A.DiffusionModel(64, 3, 50, 256, weights=w)
+    with pytest.raises(ValueError):
+        m.denoising_process(2, spatial=4, z0=torch.zeros(3, 64, 4, 4, device="cuda"))
+    with pytest.raises(_lib.LdmError):
+        m.ddim_sample(2, steps=51, spatial=4)                              # more DDIM steps than timesteps
+    with pytest.raises(RuntimeError, match="decoder_weights"):
+        m.decode(torch.zeros(1, 64, 4, 4, device="cuda"))
+    # the module still works after the rejected calls
+    assert torch.isfinite(net(torch.zeros(1, 64, 8, 8, device="cuda"), te)).all()
