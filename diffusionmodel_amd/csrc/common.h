@@ -132,6 +132,11 @@ int launch_linear_bf16(const float* in, const void* wp, const float* b, void* ou
 // NCHW f32 [B,C,H,W] in [-1,1] -> HWC u8 [B,H,W,C]: ((v + 1) * 127.5) clamped to [0,255], truncated
 // (save_as_image, src/main.rs:1297-1308)
 int launch_to_rgb8(const float* in, unsigned char* out, int B, int C, int H, int W, hipStream_t s);
+// conv3x3 / stride 1 / pad 1 from 32 real bf16 input channels (NHWC, Cpad channels per pixel) to CO <= 4 output
+// channels with an activation, written NCHW f32 [B,CO,H,W]; wfrag [9][64][8] bf16: lane (n = lane & 15,
+// g = lane >> 4) of tap t = dy*3 + dx holds W[t][g*8 + e][n], e = 0..7, zero for n >= CO
+int launch_conv3x3_fewout(const void* in, const void* wfrag, const float* bias, float* out, int B, int H, int W, int Cpad,
+                          int CO, int act, hipStream_t s);
 // forward process (src/main.rs:584-630): out[b] = x[b] * coef[t_b][0] + noise[b] * coef[t_b][1], coef [num_time][2]
 int launch_add_noise(const float* x, const float* noise, const int* t, const float* coef, int num_time, float* out, int B,
                      long per_sample, hipStream_t s);

@@ -8,6 +8,14 @@ namespace ldm {
 
 __device__ __forceinline__ bf16_t ew_f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float ew_bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
+// bf16 vectors for the MFMA kernels of this file; lin_pack2 rounds like one v_cvt_pk_bf16_f32
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lin_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lin_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int lin_pack2(float a, float b) {
+    const lin_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, lin_bf16x2));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Philox-4x32-10 and Box-Muller: four standard normals per counter.
@@ -350,6 +358,80 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const TI* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolution (stride 1, zero padding 1) from 32 bf16 channels to at most 4 output channels with an
+// activation, written NCHW f32: the last layer of the VAE decoder (32 -> 3 channels; src/main.rs:135-142,
+// 167-168 as a flipped-kernel conv).  On the tap-conv kernel this layer computes 64 padded output channels
+// for 3 real ones, writes them as f32 and needs a layout conversion afterwards.  Here D^T[16 x 16 pixels] +=
+// W[16 x 32] X[32 x 16] is one v_mfma_f32_16x16x32_bf16 per tap: the weights (rows >= CO zero) are nine
+// A fragments in registers, a workgroup stages the 18 x 18 window of a 16 x 16 tile (64 bytes per pixel) in
+// LDS, a wave owns four rows, and the lanes that hold accumulator rows 0..3 store the real channels.
+// in: NHWC bf16 [B,H,W,Cpad], wfrag: [9][64 lanes][8] bf16, out [B,CO,H,W] f32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const char* __restrict__ in, const char* __restrict__ wfrag,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                             int W, int Cpad, int CO, int act) {
+    __shared__ __attribute__((aligned(16))) char win[18 * 18 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int tiles_x = (W + 15) / 16;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int b = blockIdx.y;
+    const char* src = in + (size_t)b * H * W * Cpad * 2;
+    u32x4 wreg[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wreg[t] = *(const u32x4*)(wfrag + (t * 64 + lane) * 16);
+    for (int k = tid; k < 18 * 18 * 4; k += 256) {
+        const int p = k >> 2, piece = k & 3;
+        const int y = ty0 - 1 + p / 18, x = tx0 - 1 + p % 18;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            v = *(const u32x4*)(src + ((size_t)y * W + x) * Cpad * 2 + piece * 16);
+        *(u32x4*)(win + p * 64 + piece * 16) = v;
+    }
+    __syncthreads();
+    f32x4 binit = {0.f, 0.f, 0.f, 0.f};
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) binit[r] = r < CO ? bias[r] : 0.f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr;
+        f32x4 acc = binit;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const u32x4 xf = *(const u32x4*)(win + ((row + t / 3) * 18 + l15 + t % 3) * 64 + g * 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lin_bf16x8, wreg[t]), __builtin_bit_cast(lin_bf16x8, xf),
+                                                          acc, 0, 0, 0);
+        }
+        // lane (l15, g) holds output channels g*4 .. g*4+3 of pixel (row, l15): the real ones sit in g == 0
+        const int y = ty0 + row, x = tx0 + l15;
+        if (g == 0 && y < H && x < W) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < CO) {
+                    float v = acc[r];
+                    if (act == ACT_TANH) v = tanhf(v);
+                    else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+                    out[(((size_t)b * CO + r) * H + y) * W + x] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_conv3x3_fewout(const void* in, const void* wfrag, const float* bias, float* out, int B, int H, int W, int Cpad,
+                          int CO, int act, hipStream_t s) {
+    LDM_REQUIRE(in && wfrag && bias && out && B > 0 && B <= 65535 && H > 0 && W > 0, "bad arguments");
+    LDM_REQUIRE(CO >= 1 && CO <= 4 && Cpad >= 32 && Cpad % 8 == 0, "conv3x3_fewout serves 32 input channels and 1 to 4 output channels");
+    dim3 grid((unsigned)(((W + 15) / 16) * ((H + 15) / 16)), (unsigned)B);
+    hipLaunchKernelGGL(conv3x3_fewout_kernel, grid, dim3(256), 0, s, (const char*)in, (const char*)wfrag, bias, out, H, W, Cpad,
+                       CO, act);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
 int launch_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int Cpad, int H, int W, hipStream_t s) {
     LDM_REQUIRE(in && out && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "bad arguments");
     LDM_REQUIRE(B <= 65535, "batch too large for one launch");
@@ -437,13 +519,6 @@ int launch_linear_f32(const float* in, const float* W, const float* b, float* ou
 // once; up to 64 input rows sit in LDS as bf16 (rows XOR-swizzled per 16-byte piece) and are the B operand.
 // A wave owns 16 output columns at a time and all of K; more than 64 rows take another pass over the weights.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 lin_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float lin_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int lin_pack2(float a, float b) {
-    const lin_f32x2 f = {a, b};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, lin_bf16x2));
-}
 
 template <int NB>     // weight fragments in flight per wave (K / 32 must be a multiple)
 __global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __restrict__ in, const char* __restrict__ wp,
@@ -455,7 +530,22 @@ __global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __rest
     const int g = lane >> 4, l15 = lane & 15;
     const int KS = K / 32, PPR = K / 8;           // k-steps; 16-byte pieces per row
     const int RB = K * 2;
+    // The weight stream is cut into batches of NB fragments, batch q = (column tile q / BPN of this wave, k-steps
+    // (q % BPN) * NB ...); batch q+1 is loaded while batch q is multiplied, and batch 0 before the input rows
+    // are staged, so the stream from HBM starts with the kernel.
+    const int BPN = KS / NB;
+    const int nt0 = blockIdx.x * 4 + wave, nt_stride = gridDim.x * 4;
+    const int ntiles = nt0 < N / 16 ? (N / 16 - nt0 + nt_stride - 1) / nt_stride : 0;
+    const int nq = ntiles * BPN;
+    auto load_batch = [&](int q, u32x4 (&dst)[NB]) {
+        const int nt = nt0 + (q / BPN) * nt_stride, ks0 = (q % BPN) * NB;
+        const char* wt = wp + ((size_t)nt * KS + ks0) * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dst[j] = *(const u32x4*)(wt + (size_t)j * 1024);
+    };
     for (int m0 = 0; m0 < rows; m0 += 64) {
+        u32x4 wa[NB], wb[NB];
+        if (nq > 0) load_batch(0, wa);
         if (m0) __syncthreads();
         for (int idx = tid; idx < 64 * PPR; idx += 256) {
             const int m = idx / PPR, p = idx - m * PPR;
@@ -471,42 +561,49 @@ __global__ __launch_bounds__(256, 1) void linear_bf16_kernel(const float* __rest
             *(u32x4*)(smem_raw + m * RB + ((p ^ (m & 15)) << 4)) = v;
         }
         __syncthreads();
-        for (int nt = blockIdx.x * 4 + wave; nt < N / 16; nt += gridDim.x * 4) {
-            f32x4 acc[4];
+        f32x4 acc[4];
+        auto compute = [&](int q, const u32x4 (&a)[NB]) {
+            const int nt = nt0 + (q / BPN) * nt_stride, ks0 = (q % BPN) * NB;
+            if (ks0 == 0) {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const char* wt = wp + (size_t)nt * KS * 1024 + lane * 16;
-            for (int ks0 = 0; ks0 < KS; ks0 += NB) {
-                u32x4 a[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) a[j] = *(const u32x4*)(wt + (size_t)(ks0 + j) * 1024);
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int mf = 0; mf < 4; ++mf) {
-                        const int m = mf * 16 + l15;
-                        const u32x4 b = *(const u32x4*)(smem_raw + m * RB + ((((ks0 + j) * 4 + g) ^ l15) << 4));
-                        acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lin_bf16x8, a[j]),
-                                                                          __builtin_bit_cast(lin_bf16x8, b), acc[mf], 0, 0, 0);
-                    }
+                for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            // lane holds columns nt*16 + g*4 + (0..3) of row m0 + mf*16 + l15
-            const int n = nt * 16 + g * 4;
-            const f32x4 bv = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
-                const int m = m0 + mf * 16 + l15;
-                f32x4 v = acc[mf] + bv;
-                if (act == ACT_RELU) {
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int m = mf * 16 + l15;
+                    const u32x4 b = *(const u32x4*)(smem_raw + m * RB + ((((ks0 + j) * 4 + g) ^ l15) << 4));
+                    acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lin_bf16x8, a[j]),
+                                                                      __builtin_bit_cast(lin_bf16x8, b), acc[mf], 0, 0, 0);
                 }
-                if (m < rows) {
-                    uint2 o;
-                    o.x = lin_pack2(v[0], v[1]);
-                    o.y = lin_pack2(v[2], v[3]);
-                    *(uint2*)(out + ((size_t)m * N + n) * 2) = o;
+            if (ks0 + NB == KS) {
+                // lane holds columns nt*16 + g*4 + (0..3) of row m0 + mf*16 + l15
+                const int n = nt * 16 + g * 4;
+                const f32x4 bv = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int m = m0 + mf * 16 + l15;
+                    f32x4 v = acc[mf] + bv;
+                    if (act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (m < rows) {
+                        uint2 o;
+                        o.x = lin_pack2(v[0], v[1]);
+                        o.y = lin_pack2(v[2], v[3]);
+                        *(uint2*)(out + ((size_t)m * N + n) * 2) = o;
+                    }
                 }
+            }
+        };
+        for (int q = 0; q < nq; q += 2) {
+            if (q + 1 < nq) load_batch(q + 1, wb);
+            compute(q, wa);
+            if (q + 1 < nq) {
+                if (q + 2 < nq) load_batch(q + 2, wa);
+                compute(q + 1, wb);
             }
         }
     }

@@ -255,6 +255,8 @@ struct ldm_module {
     PackedConv rev1, rev2, rev3;
     void* lin_w = nullptr;        // transfer layer: bf16 MFMA fragments (bf16) or f32 [K][N] (f32), columns NHWC-ordered
     float* lin_b = nullptr;
+    void* rev3_w = nullptr;       // last layer for up to 4 image channels (bf16): MFMA fragments [9][64][8]
+    float* rev3_b = nullptr;
     // grow-on-demand workspace for the module-level forwards
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -526,6 +528,24 @@ static int finalize_module(ldm_module* m) {
         LDM_TRY(pack_convT(m, "reverse1", 128, 64, &m->rev1, "bn_1"));
         LDM_TRY(pack_convT(m, "reverse2", 64, 32, &m->rev2, "bn_2"));
         LDM_TRY(pack_convT3x3_s1(m, "reverse3", 32, m->te, 64, &m->rev3));
+        if (m->te <= 4 && m->dtype == LDM_BF16) {
+            // the same flipped kernel as MFMA A fragments for the direct few-channel kernel: tap (dy,dx) = (2-ky, 2-kx)
+            const int CO = m->te;
+            const std::vector<float>*w3, *b3;
+            LDM_TRY(get_param(m, "reverse3.weight", (size_t)32 * CO * 9, &w3));
+            LDM_TRY(get_param(m, "reverse3.bias", CO, &b3));
+            std::vector<bf16_t> wt((size_t)9 * 64 * 8, host_f2bf(0.f));
+            for (int tap = 0; tap < 9; ++tap)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = lane & 15, k0 = (lane >> 4) * 8;
+                    if (co >= CO) continue;
+                    for (int e = 0; e < 8; ++e)
+                        wt[((size_t)tap * 64 + lane) * 8 + e] =
+                            host_f2bf((*w3)[(((size_t)(k0 + e) * CO + co) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)]);
+                }
+            LDM_TRY(m->pool.upload(&m->rev3_w, wt.data(), wt.size() * 2));
+            LDM_TRY(m->pool.upload((void**)&m->rev3_b, b3->data(), b3->size() * 4));
+        }
     } else if (m->kind == LDM_MOD_ATTENTION) {
         LDM_TRY(pack_attention(m, "", m->in_ch, &m->mid_atten));
     } else if (m->kind == LDM_MOD_RESBLOCK) {
@@ -991,8 +1011,12 @@ int ldm_vae_decode(ldm_module* m, const float* z, float* img, int B, void* strea
     else LDM_TRY(launch_linear_f32(z, (const float*)m->lin_w, m->lin_b, (float*)y0, B, K, N, ACT_RELU, st));
     LDM_TRY(run_conv(m->rev1, y0, 128, nullptr, 0, y1, B, 16, 16, ACT_RELU, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_conv(m->rev2, y1, 64, nullptr, 0, y2, B, 32, 32, ACT_RELU, nullptr, nullptr, 0, 0, st));
-    LDM_TRY(run_conv(m->rev3, y2, 64, nullptr, 0, y3, B, 64, 64, ACT_TANH, nullptr, nullptr, 0, 1, st));
-    LDM_TRY(launch_nhwc_to_nchw(y3, LDM_F32, img, B, m->te, m->rev3.cout, 64, 64, st));
+    if (m->rev3_w) {
+        LDM_TRY(launch_conv3x3_fewout(y2, m->rev3_w, m->rev3_b, img, B, 64, 64, 64, m->te, ACT_TANH, st));
+    } else {
+        LDM_TRY(run_conv(m->rev3, y2, 64, nullptr, 0, y3, B, 64, 64, ACT_TANH, nullptr, nullptr, 0, 1, st));
+        LDM_TRY(launch_nhwc_to_nchw(y3, LDM_F32, img, B, m->te, m->rev3.cout, 64, 64, st));
+    }
     return LDM_OK;
 }
 

@@ -244,6 +244,20 @@ def test_vae_decode_small_latent(A, O, dtype):
     assert got.shape == (3, 1, 64, 64) and e < TOL[dtype]
 
 
+def test_vae_decode_many_image_channels(A, O):
+    # more than 4 image channels: the last layer runs on the tap-conv kernel instead of the direct one
+    w = A.synthetic_from_shapes(A.decoder_param_shapes(8, 64), 4)
+    torch.manual_seed(2)
+    z = torch.randn(2, 64, 4, 4)
+    ref = O.vae_decode(w, "", z)
+    _say("vae decode 8 image channels bf16")
+    got = A.Decoder(8, 64, dtype="bf16", weights=w)(z.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert got.shape == (2, 8, 64, 64) and e < TOL["bf16"]
+
+
 def test_to_rgb8_bit_exact(A, O):
     torch.manual_seed(5)
     img = torch.tanh(torch.randn(3, 3, 64, 64) * 1.5)
