@@ -1589,7 +1589,14 @@ static int launch_ws1x1(TapConvArgs& a, hipStream_t stream) {
 
 template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
-    const int bn = (a.cout % 128 == 0) ? 128 : 64;
+    int bn = (a.cout % 128 == 0) ? 128 : 64;
+    {
+        // Small problems (a few images of a few pixels): every workgroup streams all weights of its channel
+        // block through one CU, and with a handful of workgroups that stream is the whole run time.  Narrower
+        // channel blocks spread it over twice as many CUs.
+        const long t4 = (long)((a.Wg + 15) / 16) * ((a.Hg + 3) / 4) * a.B;
+        if (bn == 128 && t4 * (a.cout / 128) * pc.nphase < 64) bn = 64;
+    }
     if constexpr (sizeof(T) == 2) {
         if (ws64_shape(pc, a)) {
             if (a.sched_z) {
