@@ -66,6 +66,9 @@
 #ifndef TAPCONV_RING_L3
 #define TAPCONV_RING_L3 3
 #endif
+#ifndef TAPCONV_ALWAYS_ISSUE
+#define TAPCONV_ALWAYS_ISSUE 1
+#endif
 #ifndef TAPCONV_S2WS_128
 #define TAPCONV_S2WS_128 1
 #endif
@@ -428,7 +431,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             STAMP_ISSUE(tsA);
             const bool halo_now = t == 0 && more_chunks;
             if (halo_now) issue_halo(c + 1);      // older than slab s+D: a later counted wait covers it
+#if TAPCONV_ALWAYS_ISSUE
+            // Past the last slab the last one is issued again, into a ring slot that no later step reads: the
+            // issue stays unconditional, so the second half of this step and the first half of the next are one
+            // basic block (a branch here made the compiler wait for every LDS read in flight at the join).
+            if (!(TAPCONV_ABLATE & 2)) issue_w(s + D < nsteps ? s + D : nsteps - 1, slot == 0 ? RING - 1 : slot - 1);
+#else
             if (s + D < nsteps && !(TAPCONV_ABLATE & 2)) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
+#endif
             const unsigned wb = wbuf0 + slot * WSLAB;
             const int slot_next = slot + 1 == RING ? 0 : slot + 1;
             // first half of the next step (after the very last step this reads LDS that nobody uses:
@@ -451,7 +461,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             // s+PUB at step s+PUB-D) and step s+PUB still belongs to this chunk.
             const int need = s + PUB < nsteps - 1 ? s + PUB : nsteps - 1;
             const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
+#if TAPCONV_ALWAYS_ISSUE
+            // repeated issues of the last slab are younger than everything needed; the last step drains the queue
+            const int nrep = s + D + 1 - nsteps > 0 ? s + D + 1 - nsteps : 0;
+            const int young = (TAPCONV_ABLATE & 2) || s == nsteps - 1 ? 0 : (last - need > 0 ? last - need : 0) + nrep;
+#else
             const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - need > 0 ? last - need : 0);
+#endif
             const bool h_young = more_chunks && t <= D - 1 - PUB && t <= ntc - 1 - PUB && !(TAPCONV_ABLATE & 16);
 #ifdef TAPCONV_STAMP
             STAMP_ISSUE(tsB);        // (waits for the LDS reads as a side effect)
