@@ -297,12 +297,13 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 // attention_kernel, organised for throughput.  8 waves (two per SIMD) x QF*16 queries share every
 // 32-key K/V tile, so a tile crosses L2 -> LDS once per 128*QF queries.  Tiles go through a ring of four
 // stages and are issued two intervals ahead; waits on the DMA are counted (only the newest pieces may be in
-// flight), LDS fragment reads are ordered inline-asm reads with counted waits (a register ring three deep).
+// flight), LDS fragment reads are ordered inline-asm reads with counted waits (a register ring two deep; three
+// measured the same).
 // (Running the second wave of every SIMD half an interval out of phase, so that one wave's exponentials
 // overlap the other's MFMAs, measured no faster.)
 // ---------------------------------------------------------------------------------------------
 #ifndef ATTN_STREAM_XD
-#define ATTN_STREAM_XD 3
+#define ATTN_STREAM_XD 2
 #endif
 #ifndef ATTN_STREAM_SMALL
 #define ATTN_STREAM_SMALL 1
