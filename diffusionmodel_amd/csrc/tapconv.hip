@@ -1504,9 +1504,10 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
 }
 
 // Picks the tile height: the tallest tile that still yields at least `want` workgroups.
-static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want, bool allow16) {
-    if (allow16 && tiles16 * nblk_n * nphase >= want) return 16;
-    if (tiles8 * nblk_n * nphase >= want) return 8;
+// rows: height of the tiled grid; a tile taller than the image only multiplies zeros
+static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want, bool allow16, int rows) {
+    if (allow16 && rows > 8 && tiles16 * nblk_n * nphase >= want) return 16;
+    if (rows > 4 && tiles8 * nblk_n * nphase >= want) return 8;
     return 4;
 }
 
@@ -1642,7 +1643,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         return launch_cfg<T, 4, 64, 2, 2, 2, 3, 9, 1>(a, nph, stream);
     }
     if (pc.kind == CONV1x1) {
-        int th = pick_th(t16, t8, nblk_n, nph, 256, true);
+        int th = pick_th(t16, t8, nblk_n, nph, 256, true, a.Hg);
         if (bn == 64 && th > 8) th = 8;       // memory-bound: two workgroups per CU beat the taller tile
         if (bn == 128) {
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 1, 1, 2>(a, nph, stream);
@@ -1654,13 +1655,13 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         return launch_cfg<T, 4, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
     }
     // 3x3-window kinds: conv3x3 stride 1 (9 taps) and the convT phases (4 taps)
-    int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true);
+    int th = pick_th(t16, t8, nblk_n, nph, bn == 64 ? 512 : 256, true, a.Hg);
     if (pc.kind == CONVT4x4_S2 && bn == 64 && th > 8) th = 8;   // two workgroups per CU (LDS) beat the taller tile
     if (pc.kind == CONV3x3_S1) {
         if (bn == 128) {
             // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
             // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
-            if (th == 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L3>(a, nph, stream);
+            if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L3>(a, nph, stream);
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
