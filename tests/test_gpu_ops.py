@@ -156,6 +156,69 @@ def test_attention_running_max_jump(A, O, dtype, spike_at):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+# ---- every convolution kind through the kernel-level operator, at sizes on both sides of each ---------
+# ---- specialised kernel's dispatch threshold --------------------------------------------------------
+_CONV_CASES = [
+    # kind, B, S, cin0, cin1, cout, act, res
+    ("conv3x3", 16, 64, 64, 0, 64, None, False),        # weight-stationary 64-channel kernel, plain
+    ("conv3x3", 16, 64, 64, 0, 64, "silu", True),       # ... with residual + SiLU
+    ("conv3x3", 2, 24, 64, 0, 64, "relu", True),        # generic kernel, ragged tiles
+    ("conv3x3", 64, 32, 128, 0, 128, "silu", True),     # generic, 16-row x 128-channel tiles
+    ("conv3x3", 64, 16, 256, 0, 256, None, False),      # generic, 16-row x 64-channel tiles
+    ("conv3x3", 3, 16, 256, 0, 256, None, True),
+    ("conv3x3", 5, 4, 256, 0, 256, None, False),        # images smaller than a tile, narrow channel blocks
+    ("convT4x4_s2", 64, 16, 256, 0, 128, None, False),
+    ("convT4x4_s2", 4, 10, 128, 0, 64, "relu", False),
+    ("conv1x1", 64, 16, 256, 0, 768, None, False),      # weight-stationary 1x1 kernel
+    ("conv1x1", 64, 16, 256, 0, 256, None, True),       # ... with residual
+    ("conv1x1", 2, 12, 256, 0, 768, None, False),       # generic 1x1
+    ("conv1x1", 8, 32, 128, 128, 128, None, False),     # two sources (the concatenation is never built)
+]
+
+
+@pytest.mark.parametrize("kind,B,S,cin0,cin1,cout,act,res", _CONV_CASES)
+def test_conv_ops_against_torch(A, kind, B, S, cin0, cin1, cout, act, res):
+    """Each burn layer behind the tap-conv kernels (src/main.rs:348-366, 423-452, 460-483) against torch on
+    the same bf16-rounded operands; only the output rounding differs."""
+    import torch.nn.functional as F
+    from diffusionmodel_amd.ops import ConvOp, from_nhwc, to_nhwc
+    g = torch.Generator().manual_seed(B * 1000 + S + cout)
+    cin = cin0 + cin1
+    taps = {"conv3x3": 9, "convT4x4_s2": 4, "conv1x1": 1}[kind]
+    sc = 1.0 / (taps * cin) ** 0.5
+    if kind == "convT4x4_s2":
+        w = (torch.randn(cin, cout, 4, 4, generator=g) * sc).bfloat16().float()
+    elif kind == "conv1x1":
+        w = (torch.randn(cout, cin, generator=g) * sc).bfloat16().float()
+    else:
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * sc).bfloat16().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, S, S, generator=g).bfloat16().float()
+    if kind == "convT4x4_s2":
+        ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    elif kind == "conv1x1":
+        ref = F.conv2d(x, w.reshape(cout, cin, 1, 1), b)
+    else:
+        ref = F.conv2d(x, w, b, padding=1)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, generator=g).bfloat16().float()
+        ref = ref + r
+    if act == "silu":
+        ref = F.silu(ref)
+    elif act == "relu":
+        ref = F.relu(ref)
+    _say(f"{kind} B={B} S={S} {cin0}+{cin1}->{cout} act={act} res={res}")
+    op = ConvOp(kind, w, b, dtype="bf16", cin1=cin1)
+    x0 = to_nhwc(x[:, :cin0], "bf16").cuda()
+    x1 = to_nhwc(x[:, cin0:], "bf16").cuda() if cin1 else None
+    got = from_nhwc(op(x0, x1, res=None if r is None else to_nhwc(r, "bf16").cuda(), act=act))
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < 4e-3
+
+
 # ---- stride-2 convolutions at the sizes of the weight-stationary kernels --------------------------
 @pytest.mark.parametrize("B,S,cin,cout", [(16, 64, 64, 128), (64, 32, 128, 256), (70, 32, 128, 256), (3, 32, 128, 256)])
 def test_conv_stride2_large(A, B, S, cin, cout):
