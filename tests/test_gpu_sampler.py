@@ -49,6 +49,8 @@ def test_ddpm_chain_with_injected_noise(A, O, dtype):
     _say(f"ddpm {dtype}: eps[0] rel={e0:.3e} final z rel={efin:.3e} psnr={psnr(got_z, ref_z):.1f} dB")
     assert e0 < TOL[dtype]
     assert efin < (1e-4 if dtype == "fp32" else 5e-2)
+    # final samples: PSNR against the restatement (measured 150 dB in f32, 76 dB in bf16)
+    assert psnr(got_z, ref_z) > (100.0 if dtype == "fp32" else 50.0)
     # teacher forcing: per-step epsilon on the oracle's own z_t
     worst = 0.0
     for k in range(T):
@@ -79,6 +81,7 @@ def test_ddim_chain(A, O, dtype):
     _say(f"ddim {dtype}: eps[0] rel={e0:.3e} final rel={efin:.3e} psnr={psnr(got_z, ref_z):.1f} dB")
     assert e0 < TOL[dtype]
     assert efin < (1e-3 if dtype == "fp32" else 0.2)
+    assert psnr(got_z, ref_z) > (100.0 if dtype == "fp32" else 40.0)    # measured 146 dB / 65 dB
     zg = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
     zg2 = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
     torch.cuda.synchronize()
