@@ -72,3 +72,29 @@ def test_chain_range_partitions_the_batch():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         chain_range(8, 2, 2)
+
+
+def test_missing_library_fails_loudly():
+    """No CPU fallback: with the shared library absent every entry into the package raises."""
+    import subprocess
+    import sys
+    code = ("import diffusionmodel_amd as A\n"
+            "try:\n"
+            "    A.DiffusionModel(64, 3, 50, 256)\n"
+            "except RuntimeError as e:\n"
+            "    assert 'no CPU fallback' in str(e) or 'missing' in str(e), str(e)\n"
+            "    print('raised')\n")
+    env = dict(os.environ, LDM_HIP_LIB="/nonexistent/libldm_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "raised" in out.stdout, out.stderr[-2000:]
+
+
+def test_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under diffusionmodel_amd/ may import it."""
+    import re
+    pkg = os.path.join(ROOT, "diffusionmodel_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
