@@ -3,6 +3,7 @@
 // include/ldm_hip.h.  Reference: Unet / ResidualBlock / Attention / TimeAddition / DiffusionModel in
 // src/main.rs:237-335, 336-527, 553-583, 631-633, 681-777.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -236,6 +237,21 @@ struct UnetBufs {   // NHWC activation buffers of one forward at fixed (B, H, W)
     size_t bytes = 0;
 };
 
+// The UNet at 4x4 latents (the size the reference's VAE produces, src/main.rs:84-92) with every spatial layer
+// written as one matrix between whole images: row (input pixel, channel) -> column (output pixel, channel).
+// A 4x4, 2x2 or 1x1 image fills a sixteenth or less of a 4x16-pixel tile of the tap kernel; as matrices the
+// layers are 1x1 convolutions over a batch of B "pixels" (one per image) with 16*C, 4*C or C channels, and the
+// tiles are full.  The per-pixel layers (attention projections, up_conv1/2) keep their packed weights and run
+// on the same buffers viewed as B*P pixels.
+struct Dense4 {
+    bool ready = false;
+    PackedConv down1, down2, down3, up1, up2, out_conv;
+    PackedConv rb[7][2];
+    int tv_off[7] = {0, 0, 0, 0, 0, 0, 0};   // per block: its time vector repeated for each of its pixels
+    int tv_total = 0;
+    float *twt = nullptr, *tbt = nullptr;    // time projections with the columns repeated accordingly
+};
+
 struct ldm_module {
     int kind = 0, dtype = 0, in_ch = 0, te = 0;
     int ch[3] = {64, 128, 256};
@@ -252,6 +268,7 @@ struct ldm_module {
     float *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twt = nullptr, *tbt = nullptr;
     int tv_total = 0;
     // VAE decoder (kind LDM_MOD_VAE_DECODER): in_ch = latent_dimen, te = image channels
+    Dense4 d4;
     PackedConv rev1, rev2, rev3;
     void* lin_w = nullptr;        // transfer layer: bf16 MFMA fragments (bf16) or f32 [K][N] (f32), columns NHWC-ordered
     float* lin_b = nullptr;
@@ -472,6 +489,72 @@ static int pack_attention(ldm_module* m, const std::string& prefix, int C, AttnP
     return pack_conv(so, m->pool, &ap->out, nullptr);
 }
 
+// One spatial layer between whole Hin x Win images as a matrix (see Dense4).  kind: CONV3x3_S1 / CONV3x3_S2 with
+// weights [cout,cin,3,3] (padding 1), CONVT4x4_S2 with weights [cin,cout,4,4] (padding 1).  Channels are padded
+// to cin_pad / cout_pad per pixel, the layout of the NHWC buffers.
+static int pack_dense_layer(ldm_module* m, int kind, const std::string& name, const std::string& bn, int Hin, int Win,
+                            int cin, int cin_pad, int cout, int cout_pad, PackedConv* pc) {
+    const bool tr = kind == CONVT4x4_S2;
+    const int kk = tr ? 16 : 9, kw = tr ? 4 : 3, st = kind == CONV3x3_S1 ? 1 : 2;
+    const int Hout = tr ? Hin * 2 : Hin / st, Wout = tr ? Win * 2 : Win / st;
+    const std::vector<float>*w, *b;
+    LDM_TRY(get_param(m, pjoin(name, "weight"), (size_t)cin * cout * kk, &w));
+    LDM_TRY(get_param(m, pjoin(name, "bias"), cout, &b));
+    std::vector<float> scale, shift;
+    LDM_TRY(bn_fold(m, bn, *b, cout, &scale, &shift));
+    PackSpec sp;
+    sp.kind = CONV1x1;
+    sp.dtype = m->dtype;
+    sp.cout = Hout * Wout * cout_pad;
+    sp.src = {Hin * Win * cin_pad};
+    sp.w = [&](int, int, int n, int k) {
+        const int pi = k / cin_pad, ci = k % cin_pad, po = n / cout_pad, co = n % cout_pad;
+        if (ci >= cin || co >= cout) return 0.f;
+        const int yi = pi / Win, xi = pi % Win, yo = po / Wout, xo = po % Wout;
+        // conv: input row yi = yo*stride + ky - 1; transposed conv: output row yo = 2*yi + ky - 1
+        const int ky = tr ? yo - 2 * yi + 1 : yi - yo * st + 1, kx = tr ? xo - 2 * xi + 1 : xi - xo * st + 1;
+        if (ky < 0 || ky >= kw || kx < 0 || kx >= kw) return 0.f;
+        const size_t idx = tr ? (((size_t)ci * cout + co) * 4 + ky) * 4 + kx : (((size_t)co * cin + ci) * 3 + ky) * 3 + kx;
+        return (*w)[idx] * scale[co];
+    };
+    sp.bias = [&](int n) { const int co = n % cout_pad; return co < cout ? shift[co] : 0.f; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+// wt [te][tv] / bt [tv]: the per-block time projections side by side (block i at column m->rb[i].tv_off)
+static int pack_dense4(ldm_module* m, const std::vector<float>& wt, const std::vector<float>& bt) {
+    Dense4& d = m->d4;
+    const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2], cl = m->in_ch, te = m->te, tv = m->tv_total;
+    const int rc[7] = {c1, c2, c3, c3, c3, c2, c1};
+    const int rs[7] = {4, 2, 1, 1, 1, 2, 4};        // image side at each block
+    int off = 0;
+    for (int i = 0; i < 7; ++i) { d.tv_off[i] = off; off += rs[i] * rs[i] * rc[i]; }
+    d.tv_total = off;
+    std::vector<float> wd((size_t)te * off), bd(off);
+    for (int i = 0; i < 7; ++i)
+        for (int p = 0; p < rs[i] * rs[i]; ++p)
+            for (int c = 0; c < rc[i]; ++c) {
+                const int dst = d.tv_off[i] + p * rc[i] + c, src = m->rb[i].tv_off + c;
+                bd[dst] = bt[src];
+                for (int k = 0; k < te; ++k) wd[(size_t)k * off + dst] = wt[(size_t)k * tv + src];
+            }
+    LDM_TRY(m->pool.upload((void**)&d.twt, wd.data(), wd.size() * 4));
+    LDM_TRY(m->pool.upload((void**)&d.tbt, bd.data(), bd.size() * 4));
+    for (int i = 0; i < 7; ++i) {
+        const std::string pre = kResNames[i];
+        LDM_TRY(pack_dense_layer(m, CONV3x3_S1, pre + ".conv1", pre + ".bn1", rs[i], rs[i], rc[i], rc[i], rc[i], rc[i], &d.rb[i][0]));
+        LDM_TRY(pack_dense_layer(m, CONV3x3_S1, pre + ".conv2", pre + ".bn2", rs[i], rs[i], rc[i], rc[i], rc[i], rc[i], &d.rb[i][1]));
+    }
+    LDM_TRY(pack_dense_layer(m, CONV3x3_S1, "down1", "", 4, 4, cl, m->clp, c1, c1, &d.down1));
+    LDM_TRY(pack_dense_layer(m, CONV3x3_S2, "down2", "", 4, 4, c1, c1, c2, c2, &d.down2));
+    LDM_TRY(pack_dense_layer(m, CONV3x3_S2, "down3", "", 2, 2, c2, c2, c3, c3, &d.down3));
+    LDM_TRY(pack_dense_layer(m, CONVT4x4_S2, "up1", "", 1, 1, c3, c3, c2, c2, &d.up1));
+    LDM_TRY(pack_dense_layer(m, CONVT4x4_S2, "up2", "", 2, 2, c2, c2, c1, c1, &d.up2));
+    LDM_TRY(pack_dense_layer(m, CONV3x3_S1, "out_conv", "", 4, 4, c1, c1, cl, m->clp, &d.out_conv));
+    d.ready = true;
+    return LDM_OK;
+}
+
 static int pack_resblock(ldm_module* m, const std::string& prefix, int C, ResBlockP* rp) {
     rp->C = C;
     LDM_TRY(pack_conv3x3(m, pjoin(prefix, "conv1"), pjoin(prefix, "bn1"), C, C, 1, &rp->c1));
@@ -606,6 +689,7 @@ static int finalize_module(ldm_module* m) {
         }
         LDM_TRY(pack_conv3x3(m, "out_conv", "", c1, cl, 1, &m->out_conv));
         LDM_REQUIRE(m->out_conv.cout == m->clp, "internal: padded output and padded latent widths differ");
+        LDM_TRY(pack_dense4(m, wt, bt));
     }
     m->params.clear();
     m->finalized = true;
@@ -653,7 +737,9 @@ static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, v
     return LDM_OK;
 }
 
-static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_rows, char* base, UnetBufs* ub) {
+static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_rows, char* base, UnetBufs* ub,
+                             int tv_total = -1) {
+    if (tv_total < 0) tv_total = m->tv_total;
     const size_t es = es_of(m->dtype);
     const size_t p1 = (size_t)B * H * W, p2 = p1 / 4, p3 = p1 / 16;
     const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
@@ -673,15 +759,17 @@ static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_
     ub->sinemb = (float*)take((size_t)time_rows * m->te * 4);
     ub->h1 = (float*)take((size_t)time_rows * m->te * 8 * 4);
     ub->temb = (float*)take((size_t)time_rows * m->te * 4);
-    ub->tvec = (float*)take((size_t)time_rows * m->tv_total * 4);
+    ub->tvec = (float*)take((size_t)time_rows * tv_total * 4);
     ub->bytes = off;
     return off;
 }
 
 // time path: rows of sinusoidal embeddings -> per-block time vectors (src/main.rs:302-306, :377-378)
-static int run_time_path(const ldm_module* m, const float* sinemb, int rows, UnetBufs& ub, hipStream_t st) {
+static int run_time_path(const ldm_module* m, const float* sinemb, int rows, UnetBufs& ub, hipStream_t st,
+                         bool dense4 = false) {
     LDM_TRY(launch_linear_f32(sinemb, m->tw1, m->tb1, ub.h1, rows, m->te, m->te * 8, ACT_RELU, st));
     LDM_TRY(launch_linear_f32(ub.h1, m->tw2, m->tb2, ub.temb, rows, m->te * 8, m->te, ACT_NONE, st));
+    if (dense4) return launch_linear_f32(ub.temb, m->d4.twt, m->d4.tbt, ub.tvec, rows, m->te, m->d4.tv_total, ACT_SILU, st);
     LDM_TRY(launch_linear_f32(ub.temb, m->twt, m->tbt, ub.tvec, rows, m->te, m->tv_total, ACT_SILU, st));
     return LDM_OK;
 }
@@ -743,6 +831,51 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
     return LDM_OK;
 }
 
+// Unet::forward for Bp = 16*R images of 4x4 latents through the matrices of Dense4: every buffer [Bp, P*C] is
+// handed to the tap kernel as ONE image of R x 16 pixels with P*C channels (spatial layers) or of R*P x 16 pixels
+// with C channels (per-pixel layers).  All images share the time vector (tv.img_stride is not used).
+static int run_unet_dense4(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int Bp, const TimeVec& tv,
+                           hipStream_t st) {
+    const Dense4& d = m->d4;
+    const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
+    const int R = Bp / 16;
+    auto mat = [&](const PackedConv& pc, const void* in, void* out, int act, const void* res, int tv_off, int out_f32) {
+        return run_conv(pc, in, pc.cin, nullptr, 0, out, 1, R, 16, act, res, tv_off >= 0 ? &tv : nullptr,
+                        tv_off >= 0 ? tv_off : 0, out_f32, st);
+    };
+    auto block = [&](int i, const void* x, void* tmp, void* out) {
+        LDM_TRY(mat(d.rb[i][0], x, tmp, ACT_SILU, nullptr, d.tv_off[i], 0));
+        return mat(d.rb[i][1], tmp, out, ACT_SILU, x, -1, 0);
+    };
+    auto atten = [&](const AttnP& ap, int P, const void* x, void* qkv, void* att, void* out) {
+        LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, 1, R * P, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+        LDM_TRY(launch_attention(m->dtype, qkv, att, Bp, P, ap.C, st));
+        return run_conv(ap.out, att, ap.C, nullptr, 0, out, 1, R * P, 16, ACT_NONE, x, nullptr, 0, 0, st);
+    };
+    LDM_TRY(mat(d.down1, xin, ub.a1, ACT_NONE, nullptr, -1, 0));
+    LDM_TRY(block(0, ub.a1, ub.b1, ub.s1));
+    LDM_TRY(mat(d.down2, ub.s1, ub.a2, ACT_NONE, nullptr, -1, 0));
+    LDM_TRY(block(1, ub.a2, ub.b2, ub.s2));
+    LDM_TRY(mat(d.down3, ub.s2, ub.a3, ACT_NONE, nullptr, -1, 0));
+    LDM_TRY(block(2, ub.a3, ub.b3, ub.c3));
+    LDM_TRY(block(3, ub.c3, ub.b3, ub.a3));
+    LDM_TRY(atten(m->mid_atten, 1, ub.a3, ub.qkv3, ub.att3, ub.b3));
+    LDM_TRY(block(4, ub.b3, ub.c3, ub.a3));
+    LDM_TRY(mat(d.up1, ub.a3, ub.a2, ACT_NONE, nullptr, -1, 0));
+    LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, 1, R * 4, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(block(5, ub.b2, ub.a2, ub.s2));
+    const void* u1 = ub.s2;
+    if (m->scaled) {
+        LDM_TRY(atten(m->up_atten, 4, ub.s2, ub.qkv2, ub.att2, ub.b2));
+        u1 = ub.b2;
+    }
+    LDM_TRY(mat(d.up2, u1, ub.a1, ACT_NONE, nullptr, -1, 0));
+    LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, 1, R * 16, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(block(6, ub.b1, ub.a1, ub.s1));
+    (void)c3;
+    return mat(d.out_conv, ub.s1, eps_out, ACT_NONE, nullptr, -1, 1);
+}
+
 static int ensure_ws(ldm_module* m, size_t bytes) {
     if (bytes <= m->ws_bytes) return LDM_OK;
     if (m->ws) {
@@ -762,6 +895,8 @@ static int ensure_ws(ldm_module* m, size_t bytes) {
 struct ldm_sampler {
     ldm_module* unet = nullptr;
     int T = 0, B = 0, H = 0, W = 0;
+    bool dense4 = false;      // 4x4 latents: the layers run as matrices over whole images (Dense4)
+    int Bp = 0;               // images the buffers hold: B, or B rounded up to 16 for dense4 (the extra rows are never read out)
     DevPool pool;
     UnetBufs ub;
     float* z = nullptr;       // NHWC f32 state [B,H,W,clp]
@@ -792,13 +927,17 @@ static int sampler_step(ldm_sampler* s, int mode, bool have_noise, unsigned long
     TimeVec tv;
     tv.table = s->ub.tvec; tv.img_stride = 0; tv.step_stride = m->tv_total; tv.step_ptr = s->step;
     const void* xin = m->dtype == LDM_BF16 ? s->zl : (const void*)s->z;
-    if (mode == LDM_DDIM && !eps_trace && m->clp == 64 && tapconv_can_fuse_ddim(m->out_conv, B, H, W)) {
+    if (s->dense4) {
+        tv.step_stride = m->d4.tv_total;
+        LDM_TRY(run_unet_dense4(m, s->ub, xin, s->ub.eps, s->Bp, tv, st));
+    } else if (mode == LDM_DDIM && !eps_trace && m->clp == 64 && tapconv_can_fuse_ddim(m->out_conv, B, H, W)) {
         // the scheduler update and the step advance happen in the epilogue of the last convolution
         DdimFuse f;
         f.z = s->z; f.zl = s->zl; f.coef = s->coef; f.ctl = s->step;
         return run_unet_body(m, s->ub, xin, nullptr, B, H, W, tv, st, &f);
+    } else {
+        LDM_TRY(run_unet_body(m, s->ub, xin, s->ub.eps, B, H, W, tv, st));
     }
-    LDM_TRY(run_unet_body(m, s->ub, xin, s->ub.eps, B, H, W, tv, st));
     if (eps_trace)
         LDM_TRY(launch_nhwc_to_nchw(s->ub.eps, LDM_F32, eps_trace + (size_t)k * img, B, m->in_ch, m->out_conv.cout, H, W, st));
     SchedArgs a{};
@@ -1092,13 +1231,19 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
     LDM_REQUIRE(num_time > 0 && batch > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
     std::unique_ptr<ldm_sampler> s(new ldm_sampler());
     s->unet = unet; s->T = num_time; s->B = batch; s->H = H; s->W = W;
+    {
+        const char* e = getenv("LDM_DENSE4");      // "0": keep the tap kernels at 4x4 (for comparison runs)
+        s->dense4 = H == 4 && W == 4 && unet->d4.ready && !(e && e[0] == '0');
+    }
+    s->Bp = s->dense4 ? round_up_i(batch, 16) : batch;
+    const int tvt = s->dense4 ? unet->d4.tv_total : unet->tv_total;
     UnetBufs tmp;
-    const size_t need = plan_unet_bufs(unet, batch, H, W, num_time, nullptr, &tmp);
+    const size_t need = plan_unet_bufs(unet, s->Bp, H, W, num_time, nullptr, &tmp, tvt);
     void* arena = nullptr;
     LDM_TRY(s->pool.alloc(&arena, need));
     LDM_HIP(hipMemset(arena, 0, need));
-    plan_unet_bufs(unet, batch, H, W, num_time, (char*)arena, &s->ub);
-    const size_t nz = (size_t)batch * H * W * unet->clp;
+    plan_unet_bufs(unet, s->Bp, H, W, num_time, (char*)arena, &s->ub, tvt);
+    const size_t nz = (size_t)s->Bp * H * W * unet->clp;
     LDM_TRY(s->pool.alloc((void**)&s->z, nz * 4));
     LDM_HIP(hipMemset(s->z, 0, nz * 4));
     if (unet->dtype == LDM_BF16) {
@@ -1109,14 +1254,15 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
     LDM_TRY(s->pool.alloc((void**)&s->d_ts, (size_t)num_time * 4));
     LDM_TRY(s->pool.alloc((void**)&s->step, 32));
     LDM_HIP(hipMemset(s->step, 0, 32));
-    LDM_HIP(hipMemset(s->ub.tvec, 0, (size_t)num_time * unet->tv_total * 4));
+    LDM_HIP(hipMemset(s->ub.tvec, 0, (size_t)num_time * tvt * 4));
     LDM_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
     // one eager forward on zeros: validates the shapes and sets every kernel's launch attributes
     // before anything is captured into a graph
     TimeVec tv;
-    tv.table = s->ub.tvec; tv.step_stride = unet->tv_total; tv.step_ptr = s->step;
+    tv.table = s->ub.tvec; tv.step_stride = tvt; tv.step_ptr = s->step;
     const void* xin = unet->dtype == LDM_BF16 ? s->zl : (const void*)s->z;
-    LDM_TRY(run_unet_body(unet, s->ub, xin, s->ub.eps, batch, H, W, tv, nullptr));
+    if (s->dense4) LDM_TRY(run_unet_dense4(unet, s->ub, xin, s->ub.eps, s->Bp, tv, nullptr));
+    else LDM_TRY(run_unet_body(unet, s->ub, xin, s->ub.eps, batch, H, W, tv, nullptr));
     LDM_HIP(hipDeviceSynchronize());
     *out = s.release();
     return LDM_OK;
@@ -1170,7 +1316,7 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
     LDM_HIP(hipMemcpyAsync(s->coef, s->h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice, st));
     // time path for every visited timestep at once: [steps, tv_total] table (all chains share t)
     LDM_TRY(launch_sin_embed(s->d_ts, steps, m->te, s->ub.sinemb, st));
-    LDM_TRY(run_time_path(m, s->ub.sinemb, steps, s->ub, st));
+    LDM_TRY(run_time_path(m, s->ub.sinemb, steps, s->ub, st, s->dense4));
     if (z0) {
         LDM_TRY(launch_nchw_to_nhwc(z0, s->z, LDM_F32, B, m->in_ch, m->clp, H, W, st));
         if (m->dtype == LDM_BF16) LDM_TRY(launch_cast_f32_to_bf16(s->z, s->zl, (long)nz, st));

@@ -171,3 +171,33 @@ def test_full_size_chain_is_deterministic(A):
     other = m2.ddim_sample(64, 10, spatial=64, z0=z0, use_graph=True)
     torch.cuda.synchronize()
     assert torch.equal(eager, ref) and torch.equal(other, ref)
+
+
+@pytest.mark.parametrize("dtype,B,scaled", [("fp32", 4, False), ("fp32", 20, False), ("bf16", 20, False),
+                                            ("bf16", 64, False), ("fp32", 3, True), ("bf16", 16, True)])
+def test_whole_image_matrices_at_4x4_match_the_tap_kernels(A, O, dtype, B, scaled):
+    """At the reference's 4x4 latents the sampler runs every spatial layer as one matrix over whole images.  Its
+    per-step epsilon must agree with the tap-convolution path (noise_predict, which takes per-image times and
+    keeps the tap kernels) on the sampler's own z_t, and with the oracle; batches that are not a multiple of the
+    16 images the matrix path pads to, and the scaled UNet with its second attention (4 tokens), included."""
+    cfg = A.LDMConfig.scaled() if scaled else A.LDMConfig()
+    T, steps = 1000, 4
+    w = A.make_synthetic_weights(cfg, 11)
+    z0 = torch.randn(B, 64, 4, 4, generator=torch.Generator().manual_seed(B))
+    m = _model(A, dtype, T, w, cfg)
+    _say(f"dense4 {dtype} B={B} scaled={scaled}")
+    got_z, zt, et = m.ddim_sample(B, steps, spatial=4, z0=z0.cuda(), use_graph=False, return_trace=True)
+    torch.cuda.synchronize()
+    ts = m.ddim_timesteps(steps)
+    worst_tap, worst_ref = 0.0, 0.0
+    for k in range(steps):
+        temb = O.sin_time_addition(torch.full((B,), int(ts[k])), 256).cuda()
+        worst_tap = max(worst_tap, rel_err(et[k], m.noise_predict(zt[k], temb)))
+        worst_ref = max(worst_ref, rel_err(et[k], O.unet_forward(w, zt[k].cpu(), temb.cpu(), scaled_attention=scaled)))
+    _say(f"dense4 {dtype} B={B}: eps vs tap kernels rel={worst_tap:.3e}, vs oracle rel={worst_ref:.3e}")
+    assert worst_tap < (2e-5 if dtype == "fp32" else 2e-2)      # same arithmetic, another summation order
+    assert worst_ref < TOL[dtype]
+    zg = m.ddim_sample(B, steps, spatial=4, z0=z0.cuda(), use_graph=True)
+    zg2 = m.ddim_sample(B, steps, spatial=4, z0=z0.cuda(), use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(zg, got_z) and torch.equal(zg2, got_z)
