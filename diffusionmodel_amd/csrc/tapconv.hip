@@ -72,6 +72,9 @@
 #ifndef TAPCONV_S2WS_128
 #define TAPCONV_S2WS_128 1
 #endif
+#ifndef TAPCONV_SKINNY
+#define TAPCONV_SKINNY 1
+#endif
 #ifndef TAPCONV_L3_WM
 #define TAPCONV_L3_WM 4
 #define TAPCONV_L3_WN 2
@@ -1458,6 +1461,103 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1x1 convolution over at most 64 pixels (a Linear over a handful of rows): the sampler at the reference's
+// own sizes, batch 1-4 of 4x4 latents, where every layer is such a product and the run time is the latency of
+// streaming the weights.  The tiled kernel gives a problem like that cout/64 workgroups, each walking all
+// input chunks with a barrier per chunk.  Here a workgroup owns 16 output channels, its four waves split the
+// input chunks, and every fragment comes straight from global memory into registers (weights in the packed
+// layout: chunk slab, pair plane, row; activations: the 16-byte piece kk*4 + g of the pixel's chunk), so all
+// loads of a wave are in flight at once; the four partial sums meet in LDS.  Epilogue as in the tiled kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MF>
+__global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float part[4 * MF * 16 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int M = a.B * a.Hin * a.Win;
+    const int nchunks = a.nch0 + a.nch1;
+    const size_t slab = (size_t)a.cout * 128, plane = (size_t)a.cout * 32;
+    const char* zero = (const char*)g_zero16;
+
+    f32x4 acc[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* wl = a.w + (size_t)(g >> 1) * plane + (size_t)(n0 + l15) * 32 + (g & 1) * 16;
+    for (int c = wave; c < nchunks; c += 4) {
+        const bool s1 = c >= a.nch0;
+        const char* src = s1 ? a.in1 + (size_t)(c - a.nch0) * 128 : a.in0 + (size_t)c * 128;
+        const int pix_bytes = s1 ? a.cin1_bytes : a.cin0_bytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const u32x4 wf = *(const u32x4*)(wl + (size_t)c * slab + (size_t)kk * 2 * plane);
+            u32x4 xf[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int p = mf * 16 + l15;
+                xf[mf] = *(const u32x4*)(p < M ? src + (size_t)p * pix_bytes + (kk * 4 + g) * 16 : zero);
+            }
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
+                                                                      __builtin_bit_cast(bf16x8, xf[mf]), acc[mf], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2f(wf[q]), u2f(xf[mf][q]), acc[mf], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // acc[mf] of lane (l15, g): channels n0 + g*4 .. +3 of pixel mf*16 + l15
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) *(f32x4*)(part + ((wave * MF * 16 + mf * 16 + l15) * 16 + g * 4)) = acc[mf];
+    __syncthreads();
+    const int p = tid >> 2, cg = tid & 3;
+    if (p >= M || p >= MF * 16) return;
+    f32x4 v = *(const f32x4*)(part + (p * 16 + cg * 4));
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *(const f32x4*)(part + ((w * MF * 16 + p) * 16 + cg * 4));
+    const int co = n0 + cg * 4;
+    v += *(const f32x4*)(a.bias + co);
+    const size_t eo = (size_t)p * a.cout + co;
+    if (a.res) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 r = *(const uint2*)(a.res + eo * 2);
+            v[0] += bf2f((bf16_t)(r.x & 0xffffu)); v[1] += bf2f((bf16_t)(r.x >> 16));
+            v[2] += bf2f((bf16_t)(r.y & 0xffffu)); v[3] += bf2f((bf16_t)(r.y >> 16));
+        } else {
+            v += *(const f32x4*)(a.res + eo * 4);
+        }
+    }
+    if (a.act == ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = silu_f<sizeof(T) == 4>(v[q]);
+    } else if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    } else if (a.act == ACT_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+    }
+    if (a.tvec) {
+        const int step = a.step_ptr ? *a.step_ptr : 0;
+        const int img = p / (a.Hin * a.Win);
+        v += *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co);
+    }
+    if (sizeof(T) == 4 || a.out_f32) {
+        *(f32x4*)(a.out + eo * 4) = v;
+    } else {
+        uint2 o;
+        o.x = pack2(v[0], v[1]);
+        o.y = pack2(v[2], v[3]);
+        *(uint2*)(a.out + eo * 2) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -1605,6 +1705,17 @@ static int launch_ws1x1(TapConvArgs& a, hipStream_t stream) {
 }
 
 template <typename T>
+static int launch_skinny1x1(TapConvArgs& a, hipStream_t stream) {
+    const int M = a.B * a.Hin * a.Win;
+    const dim3 grid((unsigned)(a.cout / 16)), block(256);
+    if (M <= 16) hipLaunchKernelGGL((skinny1x1_kernel<T, 1>), grid, block, 0, stream, a);
+    else if (M <= 32) hipLaunchKernelGGL((skinny1x1_kernel<T, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((skinny1x1_kernel<T, 4>), grid, block, 0, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     int bn = (a.cout % 128 == 0) ? 128 : 64;
     {
@@ -1626,6 +1737,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         }
     }
     if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
+    if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= 64 && TAPCONV_SKINNY) return launch_skinny1x1<T>(a, stream);
     if constexpr (sizeof(T) == 2) {
         if (s2ws_shape(pc, a) && a.act == ACT_NONE && !a.res && !a.tvec && !a.out_f32) return launch_s2ws(a, stream);
         if (ws1x1_shape(pc, a) && a.act == ACT_NONE && !a.tvec && !a.out_f32)
