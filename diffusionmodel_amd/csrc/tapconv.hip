@@ -72,8 +72,8 @@
 #ifndef TAPCONV_S2WS_128
 #define TAPCONV_S2WS_128 1
 #endif
-#ifndef TAPCONV_SKINNY
-#define TAPCONV_SKINNY 1
+#ifndef TAPCONV_SKINNY_MAXM
+#define TAPCONV_SKINNY_MAXM 512      // 1x1 convolutions over at most this many pixels take the skinny kernel
 #endif
 #ifndef TAPCONV_L3_WM
 #define TAPCONV_L3_WM 4
@@ -1461,10 +1461,10 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1x1 convolution over at most 64 pixels (a Linear over a handful of rows): the sampler at the reference's
-// own sizes, batch 1-4 of 4x4 latents, where every layer is such a product and the run time is the latency of
+// 1x1 convolution over a few pixels (a Linear over a handful of rows): the sampler at the reference's own
+// sizes, batch 1-4 of 4x4 latents, where every layer is such a product and the run time is the latency of
 // streaming the weights.  The tiled kernel gives a problem like that cout/64 workgroups, each walking all
-// input chunks with a barrier per chunk.  Here a workgroup owns 16 output channels, its four waves split the
+// input chunks with a barrier per chunk.  Here a workgroup owns 16 output channels of up to 64 pixels, its four waves split the
 // input chunks, and every fragment comes straight from global memory into registers (weights in the packed
 // layout: chunk slab, pair plane, row; activations: the 16-byte piece kk*4 + g of the pixel's chunk), so all
 // loads of a wave are in flight at once; the four partial sums meet in LDS.  Epilogue as in the tiled kernel.
@@ -1476,6 +1476,7 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int n0 = blockIdx.x * 16;
+    const int p0 = blockIdx.y * (MF * 16);           // first pixel of this workgroup
     const int M = a.B * a.Hin * a.Win;
     const int nchunks = a.nch0 + a.nch1;
     const size_t slab = (size_t)a.cout * 128, plane = (size_t)a.cout * 32;
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
             u32x4 xf[MF];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                const int p = mf * 16 + l15;
+                const int p = p0 + mf * 16 + l15;
                 xf[mf] = *(const u32x4*)(p < M ? src + (size_t)p * pix_bytes + (kk * 4 + g) * 16 : zero);
             }
 #pragma unroll
@@ -1515,11 +1516,12 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) *(f32x4*)(part + ((wave * MF * 16 + mf * 16 + l15) * 16 + g * 4)) = acc[mf];
     __syncthreads();
-    const int p = tid >> 2, cg = tid & 3;
-    if (p >= M || p >= MF * 16) return;
-    f32x4 v = *(const f32x4*)(part + (p * 16 + cg * 4));
+    const int pl = tid >> 2, cg = tid & 3;
+    const int p = p0 + pl;
+    if (p >= M || pl >= MF * 16) return;
+    f32x4 v = *(const f32x4*)(part + (pl * 16 + cg * 4));
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *(const f32x4*)(part + ((w * MF * 16 + p) * 16 + cg * 4));
+    for (int w = 1; w < 4; ++w) v += *(const f32x4*)(part + ((w * MF * 16 + pl) * 16 + cg * 4));
     const int co = n0 + cg * 4;
     v += *(const f32x4*)(a.bias + co);
     const size_t eo = (size_t)p * a.cout + co;
@@ -1707,10 +1709,10 @@ static int launch_ws1x1(TapConvArgs& a, hipStream_t stream) {
 template <typename T>
 static int launch_skinny1x1(TapConvArgs& a, hipStream_t stream) {
     const int M = a.B * a.Hin * a.Win;
-    const dim3 grid((unsigned)(a.cout / 16)), block(256);
-    if (M <= 16) hipLaunchKernelGGL((skinny1x1_kernel<T, 1>), grid, block, 0, stream, a);
-    else if (M <= 32) hipLaunchKernelGGL((skinny1x1_kernel<T, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((skinny1x1_kernel<T, 4>), grid, block, 0, stream, a);
+    const dim3 block(256);
+    if (M <= 16) hipLaunchKernelGGL((skinny1x1_kernel<T, 1>), dim3((unsigned)(a.cout / 16), 1), block, 0, stream, a);
+    else if (M <= 32) hipLaunchKernelGGL((skinny1x1_kernel<T, 2>), dim3((unsigned)(a.cout / 16), 1), block, 0, stream, a);
+    else hipLaunchKernelGGL((skinny1x1_kernel<T, 4>), dim3((unsigned)(a.cout / 16), (unsigned)((M + 63) / 64)), block, 0, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }
@@ -1737,7 +1739,8 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         }
     }
     if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
-    if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= 64 && TAPCONV_SKINNY) return launch_skinny1x1<T>(a, stream);
+    // measured at 1024 -> 1024 channels: 145 vs 206 us per sampler step at 256 pixels, a tie at 1024, half the speed at 4096
+    if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= TAPCONV_SKINNY_MAXM) return launch_skinny1x1<T>(a, stream);
     if constexpr (sizeof(T) == 2) {
         if (s2ws_shape(pc, a) && a.act == ACT_NONE && !a.res && !a.tvec && !a.out_f32) return launch_s2ws(a, stream);
         if (ws1x1_shape(pc, a) && a.act == ACT_NONE && !a.tvec && !a.out_f32)

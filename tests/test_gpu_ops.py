@@ -173,6 +173,9 @@ _CONV_CASES = [
     ("conv1x1", 64, 16, 256, 0, 256, None, True),       # ... with residual
     ("conv1x1", 2, 12, 256, 0, 768, None, False),       # generic 1x1
     ("conv1x1", 8, 32, 128, 128, 128, None, False),     # two sources (the concatenation is never built)
+    ("conv1x1", 1, 3, 1024, 0, 512, "silu", True),      # a few pixels: the skinny kernel, one 16-pixel fragment, ragged
+    ("conv1x1", 3, 5, 128, 128, 192, "relu", False),    # ... 75 pixels over two workgroup rows, two sources
+    ("conv1x1", 7, 8, 256, 0, 64, None, True),          # ... 448 pixels
 ]
 
 
