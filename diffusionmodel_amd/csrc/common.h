@@ -79,6 +79,7 @@ struct ConvCall {
     const void* in0 = nullptr;   // NHWC [B,Hin,Win,cin0]
     const void* in1 = nullptr;   // optional second source (channels appended after in0's)
     int cin0 = 0, cin1 = 0;
+    int in0_stride = 0;          // channels between consecutive pixels of in0 when it is a slice of a wider tensor (0: cin0)
     const void* res = nullptr;   // NHWC [B,Hout,Wout,cout], added before the activation
     const float* tvec = nullptr; // added after the activation: tvec[img*t_img_stride + step*t_step_stride + c]
     const int* step_ptr = nullptr;

@@ -849,6 +849,15 @@ static int run_unet_dense4(const ldm_module* m, UnetBufs& ub, const void* xin, v
     };
     auto atten = [&](const AttnP& ap, int P, const void* x, void* qkv, void* att, void* out) {
         LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, 1, R * P, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+        if (P == 1) {
+            // one token: its soft-max weight is exp(0) / exp(0) = 1 exactly, the attention output is the value row
+            // itself; the out projection reads it in place (channels 2C .. 3C of every q|k|v row)
+            ConvCall cc;
+            cc.in0 = (const char*)qkv + (size_t)2 * ap.C * es_of(m->dtype);
+            cc.cin0 = ap.C; cc.in0_stride = 3 * ap.C;
+            cc.out = out; cc.res = x; cc.B = 1; cc.Hin = R; cc.Win = 16;
+            return launch_tapconv(ap.out, cc, st);
+        }
         LDM_TRY(launch_attention(m->dtype, qkv, att, Bp, P, ap.C, st));
         return run_conv(ap.out, att, ap.C, nullptr, 0, out, 1, R * P, 16, ACT_NONE, x, nullptr, 0, 0, st);
     };

@@ -36,6 +36,7 @@
 // bf16 uses v_mfma_f32_16x16x32_bf16; f32 uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) four times
 // per 16-byte fragment, with the K permutation applied identically to both operands.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1482,6 +1483,31 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
     const size_t slab = (size_t)a.cout * 128, plane = (size_t)a.cout * 32;
     const char* zero = (const char*)g_zero16;
 
+    // Epilogue operands of this thread (pixel p0 + tid/4, channels n0 + (tid&3)*4 .. +3), loaded before the
+    // main loop: behind it they would add a dependent round trip to memory (step counter -> time vector) to a
+    // kernel that lasts three.
+    const int pl = tid >> 2, cg = tid & 3;
+    const int p = p0 + pl;
+    const bool mine = p < M && pl < MF * 16;
+    const int co = n0 + cg * 4;
+    const size_t eo = (size_t)(mine ? p : 0) * a.cout + co;
+    const f32x4 bias = *(const f32x4*)(a.bias + co);
+    f32x4 resv = {0.f, 0.f, 0.f, 0.f}, tv = {0.f, 0.f, 0.f, 0.f};
+    if (a.res) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 r = *(const uint2*)(a.res + eo * 2);
+            resv[0] = bf2f((bf16_t)(r.x & 0xffffu)); resv[1] = bf2f((bf16_t)(r.x >> 16));
+            resv[2] = bf2f((bf16_t)(r.y & 0xffffu)); resv[3] = bf2f((bf16_t)(r.y >> 16));
+        } else {
+            resv = *(const f32x4*)(a.res + eo * 4);
+        }
+    }
+    if (a.tvec) {
+        const int step = a.step_ptr ? *a.step_ptr : 0;
+        const int img = (mine ? p : 0) / (a.Hin * a.Win);
+        tv = *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co);
+    }
+
     f32x4 acc[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1496,8 +1522,8 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
             u32x4 xf[MF];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                const int p = p0 + mf * 16 + l15;
-                xf[mf] = *(const u32x4*)(p < M ? src + (size_t)p * pix_bytes + (kk * 4 + g) * 16 : zero);
+                const int q = p0 + mf * 16 + l15;
+                xf[mf] = *(const u32x4*)(q < M ? src + (size_t)q * pix_bytes + (kk * 4 + g) * 16 : zero);
             }
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
@@ -1512,28 +1538,16 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
             }
         }
     }
-    // acc[mf] of lane (l15, g): channels n0 + g*4 .. +3 of pixel mf*16 + l15
+    // acc[mf] of lane (l15, g): channels n0 + g*4 .. +3 of pixel p0 + mf*16 + l15
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) *(f32x4*)(part + ((wave * MF * 16 + mf * 16 + l15) * 16 + g * 4)) = acc[mf];
     __syncthreads();
-    const int pl = tid >> 2, cg = tid & 3;
-    const int p = p0 + pl;
-    if (p >= M || pl >= MF * 16) return;
+    if (!mine) return;
     f32x4 v = *(const f32x4*)(part + (pl * 16 + cg * 4));
 #pragma unroll
     for (int w = 1; w < 4; ++w) v += *(const f32x4*)(part + ((w * MF * 16 + pl) * 16 + cg * 4));
-    const int co = n0 + cg * 4;
-    v += *(const f32x4*)(a.bias + co);
-    const size_t eo = (size_t)p * a.cout + co;
-    if (a.res) {
-        if constexpr (sizeof(T) == 2) {
-            const uint2 r = *(const uint2*)(a.res + eo * 2);
-            v[0] += bf2f((bf16_t)(r.x & 0xffffu)); v[1] += bf2f((bf16_t)(r.x >> 16));
-            v[2] += bf2f((bf16_t)(r.y & 0xffffu)); v[3] += bf2f((bf16_t)(r.y >> 16));
-        } else {
-            v += *(const f32x4*)(a.res + eo * 4);
-        }
-    }
+    v += bias;
+    v += resv;
     if (a.act == ACT_SILU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = silu_f<sizeof(T) == 4>(v[q]);
@@ -1544,11 +1558,7 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
     }
-    if (a.tvec) {
-        const int step = a.step_ptr ? *a.step_ptr : 0;
-        const int img = p / (a.Hin * a.Win);
-        v += *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co);
-    }
+    v += tv;
     if (sizeof(T) == 4 || a.out_f32) {
         *(f32x4*)(a.out + eo * 4) = v;
     } else {
@@ -1635,7 +1645,7 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
 // The shapes the weight-stationary kernel serves: 64 -> 64 channels, bf16, exact 8x16 tiling, at least
 // one tile per workgroup slot of the chip.
 static bool ws64_shape(const PackedConv& pc, const TapConvArgs& a) {
-    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 &&
+    return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 &&
            a.Hg % 8 == 0 && a.Wg % 16 == 0 && (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
 }
 
@@ -1646,7 +1656,7 @@ bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
 
 static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
     const bool c64 = a.nch0 == 1 && a.cout == 128, c128 = a.nch0 == 2 && a.cout == 256;
-    return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || (c128 && TAPCONV_S2WS_128)) && a.nch1 == 0 &&
+    return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || (c128 && TAPCONV_S2WS_128)) && a.nch1 == 0 &&
            a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
 }
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
@@ -1683,7 +1693,7 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 
 static bool ws1x1_shape(const PackedConv& pc, const TapConvArgs& a) {
     const long px = (long)a.B * a.Hin * a.Win;
-    return pc.dtype == LDM_BF16 && pc.kind == CONV1x1 && a.nch0 == 4 && a.nch1 == 0 && a.cout % 256 == 0 && px % 32 == 0 &&
+    return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV1x1 && a.nch0 == 4 && a.nch1 == 0 && a.cout % 256 == 0 && px % 32 == 0 &&
            px / 32 >= 512 && !TAPCONV_NO_WS64;
 }
 
@@ -1853,7 +1863,7 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     LDM_REQUIRE(pc.cout % 64 == 0, "output channels must be padded to a multiple of 64");
     LDM_REQUIRE(cc.B > 0 && cc.Hin > 0 && cc.Win > 0, "empty input");
     LDM_REQUIRE((cc.cin1 == 0) == (cc.in1 == nullptr), "second source and its channel count disagree");
-    LDM_REQUIRE((size_t)cc.Hin * cc.Win * (size_t)(cc.cin0 > cc.cin1 ? cc.cin0 : cc.cin1) * es < (1ull << 31), "image too large");
+    LDM_REQUIRE((size_t)cc.Hin * cc.Win * (size_t)std::max(std::max(cc.cin0, cc.in0_stride), cc.cin1) * es < (1ull << 31), "image too large");
     if (pc.ntaps1 != pc.ntaps)   // the second source has the output's resolution
         LDM_REQUIRE((size_t)4 * cc.Hin * cc.Win * (size_t)cc.cin1 * es < (1ull << 31), "image too large");
     TapConvArgs a{};
@@ -1862,7 +1872,8 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     a.res = (const char*)cc.res; a.tvec = cc.tvec; a.step_ptr = cc.step_ptr;
     a.out = (char*)cc.out;
     a.nch0 = cc.cin0 / ck; a.nch1 = cc.cin1 / ck;
-    a.cin0_bytes = cc.cin0 * es; a.cin1_bytes = cc.cin1 * es;
+    LDM_REQUIRE(cc.in0_stride == 0 || (cc.in0_stride >= cc.cin0 && cc.in0_stride % (16 / es) == 0), "bad pixel stride of the first source");
+    a.cin0_bytes = (cc.in0_stride ? cc.in0_stride : cc.cin0) * es; a.cin1_bytes = cc.cin1 * es;
     a.B = cc.B; a.Hin = cc.Hin; a.Win = cc.Win;
     LDM_TRY(conv_out_hw(pc.kind, cc.Hin, cc.Win, &a.Hout, &a.Wout));
     a.osc = pc.kind == CONVT4x4_S2 ? 2 : 1;
