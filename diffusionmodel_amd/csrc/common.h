@@ -81,9 +81,10 @@ struct ConvCall {
     int cin0 = 0, cin1 = 0;
     int in0_stride = 0;          // channels between consecutive pixels of in0 when it is a slice of a wider tensor (0: cin0)
     const void* res = nullptr;   // NHWC [B,Hout,Wout,cout], added before the activation
-    const float* tvec = nullptr; // added after the activation: tvec[img*t_img_stride + step*t_step_stride + c]
+    const float* tvec = nullptr; // added after the activation: tvec[img*t_img_stride + pixel*t_pix_stride + step*t_step_stride + c]
     const int* step_ptr = nullptr;
     int t_img_stride = 0, t_step_stride = 0;
+    int t_pix_stride = 0;        // further offset per pixel of the image (a batch handed over as one image of B pixels)
     void* out = nullptr;         // NHWC [B,Hout,Wout,cout]
     int out_f32 = 0;             // write f32 although dtype is bf16
     int act = ACT_NONE;

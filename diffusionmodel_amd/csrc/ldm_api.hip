@@ -702,6 +702,7 @@ static int finalize_module(ldm_module* m) {
 struct TimeVec {   // where the per-block time vectors come from
     const float* table = nullptr;
     int img_stride = 0, step_stride = 0;
+    int pix_stride = 0;   // whole-image matrices: the batch is one image of B pixels, each with its own row
     const int* step_ptr = nullptr;
 };
 
@@ -715,6 +716,7 @@ static int run_conv(const PackedConv& pc, const void* in0, int cin0, const void*
         cc.tvec = tv->table + tv_off;
         cc.t_img_stride = tv->img_stride;
         cc.t_step_stride = tv->step_stride;
+        cc.t_pix_stride = tv->pix_stride;
         cc.step_ptr = tv->step_ptr;
     }
     return launch_tapconv(pc, cc, st);
@@ -883,6 +885,12 @@ static int run_unet_dense4(const ldm_module* m, UnetBufs& ub, const void* xin, v
     LDM_TRY(block(6, ub.b1, ub.a1, ub.s1));
     (void)c3;
     return mat(d.out_conv, ub.s1, eps_out, ACT_NONE, nullptr, -1, 1);
+}
+
+// 4x4 latents run as whole-image matrices unless LDM_DENSE4=0 asks for the tap kernels (comparison runs, tests)
+static bool use_dense4(const ldm_module* m, int H, int W) {
+    const char* e = getenv("LDM_DENSE4");
+    return H == 4 && W == 4 && m->d4.ready && !(e && e[0] == '0');
 }
 
 static int ensure_ws(ldm_module* m, size_t bytes) {
@@ -1069,6 +1077,19 @@ int ldm_unet_forward(ldm_module* m, const float* x, const float* time_emb, float
     LDM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
     hipStream_t st = (hipStream_t)stream;
     UnetBufs ub;
+    if (use_dense4(m, H, W)) {
+        // rows B .. Bp-1 of every buffer are padding: computed from whatever they hold, never read out
+        const int Bp = round_up_i(B, 16);
+        const size_t need = plan_unet_bufs(m, Bp, H, W, Bp, nullptr, &ub, m->d4.tv_total);
+        LDM_TRY(ensure_ws(m, need));
+        plan_unet_bufs(m, Bp, H, W, Bp, (char*)m->ws, &ub, m->d4.tv_total);
+        LDM_TRY(run_time_path(m, time_emb, B, ub, st, true));
+        LDM_TRY(launch_nchw_to_nhwc(x, ub.xin, m->dtype, B, m->in_ch, m->clp, H, W, st));
+        TimeVec tv;
+        tv.table = ub.tvec; tv.pix_stride = m->d4.tv_total;
+        LDM_TRY(run_unet_dense4(m, ub, ub.xin, ub.eps, Bp, tv, st));
+        return launch_nhwc_to_nchw(ub.eps, LDM_F32, eps, B, m->in_ch, m->out_conv.cout, H, W, st);
+    }
     const size_t need = plan_unet_bufs(m, B, H, W, B, nullptr, &ub);
     LDM_TRY(ensure_ws(m, need));
     plan_unet_bufs(m, B, H, W, B, (char*)m->ws, &ub);
@@ -1240,10 +1261,7 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
     LDM_REQUIRE(num_time > 0 && batch > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
     std::unique_ptr<ldm_sampler> s(new ldm_sampler());
     s->unet = unet; s->T = num_time; s->B = batch; s->H = H; s->W = W;
-    {
-        const char* e = getenv("LDM_DENSE4");      // "0": keep the tap kernels at 4x4 (for comparison runs)
-        s->dense4 = H == 4 && W == 4 && unet->d4.ready && !(e && e[0] == '0');
-    }
+    s->dense4 = use_dense4(unet, H, W);
     s->Bp = s->dense4 ? round_up_i(batch, 16) : batch;
     const int tvt = s->dense4 ? unet->d4.tv_total : unet->tv_total;
     UnetBufs tmp;

@@ -104,7 +104,7 @@ struct TapConvArgs {
     int ntaps;
     int tiles_x, tiles_y, ntiles, nblk_n, nphase;
     int act, out_f32;
-    int t_img_stride, t_step_stride;
+    int t_img_stride, t_step_stride, t_pix_stride;
     long w_phase_stride;         // bytes
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
@@ -565,6 +565,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         f32x4 v0 = *(const f32x4*)(smem + p * RS + cg * 32) + b0;
         f32x4 v1 = *(const f32x4*)(smem + p * RS + cg * 32 + 16) + b1;
         if (a.res) { v0 += r0[i]; v1 += r1[i]; }
+        if (a.t_pix_stride) {      // a time vector per pixel (uniform branch; rare)
+            const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+            const float* tp = tv + (size_t)((gy < a.Hg ? gy : a.Hg - 1) * a.Wg + (gx < a.Wg ? gx : a.Wg - 1)) * a.t_pix_stride;
+            t0 = *(const f32x4*)tp;
+            t1 = *(const f32x4*)(tp + 4);
+        }
         if (a.act == ACT_SILU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v0[q] = silu_f<sizeof(T) == 4>(v0[q]); v1[q] = silu_f<sizeof(T) == 4>(v1[q]); }
@@ -1505,7 +1511,9 @@ __global__ __launch_bounds__(256) void skinny1x1_kernel(const TapConvArgs a) {
     if (a.tvec) {
         const int step = a.step_ptr ? *a.step_ptr : 0;
         const int img = (mine ? p : 0) / (a.Hin * a.Win);
-        tv = *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co);
+        const int pin = (mine ? p : 0) - img * (a.Hin * a.Win);
+        tv = *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)pin * a.t_pix_stride +
+                             (size_t)step * a.t_step_stride + co);
     }
 
     f32x4 acc[MF];
@@ -1881,7 +1889,8 @@ int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream)
     a.cout = pc.cout;
     a.ntaps = pc.ntaps;
     a.act = cc.act; a.out_f32 = (pc.dtype == LDM_F32) ? 1 : cc.out_f32;
-    a.t_img_stride = cc.t_img_stride; a.t_step_stride = cc.t_step_stride;
+    a.t_img_stride = cc.t_img_stride; a.t_step_stride = cc.t_step_stride; a.t_pix_stride = cc.t_pix_stride;
+    LDM_REQUIRE(cc.t_pix_stride == 0 || (pc.kind == CONV1x1 && cc.tvec), "a time vector per pixel is a 1x1-convolution feature");
     a.sched_z = cc.ddim_z; a.sched_coef = cc.ddim_coef; a.sched_ticket = cc.ddim_ticket;
     LDM_REQUIRE(!cc.ddim_z || (cc.ddim_coef && cc.step_ptr), "fused DDIM update needs the coefficient table and the step counter");
     a.w_phase_stride = ((long)a.nch0 * pc.ntaps + (long)a.nch1 * pc.ntaps1) * pc.cout * 128;

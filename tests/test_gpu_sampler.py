@@ -151,6 +151,24 @@ def test_ddim_fused_update_large_latent(A, O):
         assert torch.equal(zg, fused)
 
 
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def _tap_kernels_at_4x4():
+    """The library reads LDM_DENSE4 at every call: "0" keeps the tap kernels at 4x4 latents."""
+    old = os.environ.get("LDM_DENSE4")
+    os.environ["LDM_DENSE4"] = "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["LDM_DENSE4"]
+        else:
+            os.environ["LDM_DENSE4"] = old
+
+
 def test_full_size_chain_is_deterministic(A):
     """[64,64,64,64] bf16 DDIM, the benchmark's shape: every launch of the loop runs the weight-stationary and
     fused kernels whose waits are counted by hand.  Replays of the graph, an eager run, and a second model built
@@ -177,8 +195,8 @@ def test_full_size_chain_is_deterministic(A):
                                             ("bf16", 64, False), ("fp32", 3, True), ("bf16", 16, True)])
 def test_whole_image_matrices_at_4x4_match_the_tap_kernels(A, O, dtype, B, scaled):
     """At the reference's 4x4 latents the sampler runs every spatial layer as one matrix over whole images.  Its
-    per-step epsilon must agree with the tap-convolution path (noise_predict, which takes per-image times and
-    keeps the tap kernels) on the sampler's own z_t, and with the oracle; batches that are not a multiple of the
+    per-step epsilon must agree with the tap-convolution path (noise_predict with LDM_DENSE4=0) on the sampler's
+    own z_t, and with the oracle; batches that are not a multiple of the
     16 images the matrix path pads to, and the scaled UNet with its second attention (4 tokens), included."""
     cfg = A.LDMConfig.scaled() if scaled else A.LDMConfig()
     T, steps = 1000, 4
@@ -192,7 +210,10 @@ def test_whole_image_matrices_at_4x4_match_the_tap_kernels(A, O, dtype, B, scale
     worst_tap, worst_ref = 0.0, 0.0
     for k in range(steps):
         temb = O.sin_time_addition(torch.full((B,), int(ts[k])), 256).cuda()
-        worst_tap = max(worst_tap, rel_err(et[k], m.noise_predict(zt[k], temb)))
+        with _tap_kernels_at_4x4():
+            tap = m.noise_predict(zt[k], temb)
+            torch.cuda.synchronize()
+        worst_tap = max(worst_tap, rel_err(et[k], tap))
         worst_ref = max(worst_ref, rel_err(et[k], O.unet_forward(w, zt[k].cpu(), temb.cpu(), scaled_attention=scaled)))
     _say(f"dense4 {dtype} B={B}: eps vs tap kernels rel={worst_tap:.3e}, vs oracle rel={worst_ref:.3e}")
     assert worst_tap < (2e-5 if dtype == "fp32" else 2e-2)      # same arithmetic, another summation order
@@ -201,3 +222,27 @@ def test_whole_image_matrices_at_4x4_match_the_tap_kernels(A, O, dtype, B, scale
     zg2 = m.ddim_sample(B, steps, spatial=4, z0=z0.cuda(), use_graph=True)
     torch.cuda.synchronize()
     assert torch.equal(zg, got_z) and torch.equal(zg2, got_z)
+
+
+@pytest.mark.parametrize("dtype,B", [("fp32", 5), ("bf16", 37), ("bf16", 300)])
+def test_noise_predict_at_4x4_with_a_time_per_image(A, O, dtype, B):
+    """noise_predict on 4x4 latents (the training forward of the reference, src/main.rs:653-655, draws a timestep
+    per image): the whole-image matrices with one time-vector row per image, against the tap kernels and the
+    oracle.  B is not a multiple of 16; 300 images take the tiled 1x1 kernel, the others the skinny one."""
+    w = A.make_synthetic_weights(A.LDMConfig(), 3)
+    g = torch.Generator().manual_seed(B)
+    z = torch.randn(B, 64, 4, 4, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    temb = O.sin_time_addition(t, 256)
+    m = _model(A, dtype, 1000, w)
+    _say(f"noise_predict 4x4 {dtype} B={B}")
+    got = m.noise_predict(z.cuda(), temb.cuda())
+    torch.cuda.synchronize()
+    with _tap_kernels_at_4x4():
+        tap = m.noise_predict(z.cuda(), temb.cuda())
+        torch.cuda.synchronize()
+    ref = O.unet_forward(w, z, temb)
+    e_tap, e_ref = rel_err(got, tap), rel_err(got, ref)
+    _say(f"noise_predict 4x4 {dtype} B={B}: vs tap kernels rel={e_tap:.3e}, vs oracle rel={e_ref:.3e}")
+    assert e_tap < (2e-5 if dtype == "fp32" else 2e-2) and e_ref < TOL[dtype]
+    assert e_tap > 0 or dtype == "fp32"       # the two paths really are different code
