@@ -136,7 +136,10 @@ int ldm_sched_step(float* z_dev, const float* eps_dev, const float* noise_dev, l
 
 /* ---- the sampling loop: DiffusionModel::denoising_process, src/main.rs:681-777 ------------ */
 /* The loop runs on `batch` independent chains of shape [in_channels,H,W]; the trailing vae.decode
- * (:786) is outside this library.  All per-call memory is allocated by ldm_sampler_create. */
+ * (:786) is outside this library.  All per-call memory is allocated by ldm_sampler_create.
+ * At H = W = 4, the latent size of the reference's VAE, the sampler (and ldm_unet_forward) runs every
+ * spatial layer as one matrix between whole images, built at ldm_module_finalize; the environment variable
+ * LDM_DENSE4=0, read at each call, keeps the tiled convolution kernels at that size instead. */
 int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int batch, int H, int W);
 /* mode LDM_DDPM visits i = num_time-1 .. 0; LDM_DDIM visits ddim_steps strided timesteps.
  * z0_dev   [batch,C,H,W] initial latent, or NULL: drawn from the counter-based generator.
