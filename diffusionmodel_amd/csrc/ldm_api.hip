@@ -247,6 +247,10 @@ struct Dense4 {
     bool ready = false;
     PackedConv down1, down2, down3, up1, up2, out_conv;
     PackedConv rb[7][2];
+    // compositions of consecutive linear layers, for batches small enough that a launch costs more than its FLOPs:
+    // up1 . up_conv1 and up2 . up_conv2 over the sources {x, skip}, and the attention block at one token per image
+    // (soft-max weight 1): out(val(x)) + x as one matrix
+    PackedConv up1c, up2c, att1;
     int tv_off[7] = {0, 0, 0, 0, 0, 0, 0};   // per block: its time vector repeated for each of its pixels
     int tv_total = 0;
     float *twt = nullptr, *tbt = nullptr;    // time projections with the columns repeated accordingly
@@ -257,6 +261,7 @@ struct ldm_module {
     int ch[3] = {64, 128, 256};
     bool scaled = false, finalized = false;
     std::map<std::string, std::vector<float>> params;
+    std::map<std::string, std::pair<std::vector<float>, std::vector<float>>> composed;   // compose_up results, until finalize ends
     DevPool pool;
     // packed network
     int clp = 0;   // latent channels padded to the kernel's channel chunk
@@ -409,6 +414,38 @@ static int pack_conv1x1_cat(ldm_module* m, const std::string& name, int cin0, in
     return pack_conv(sp, m->pool, pc, nullptr);
 }
 
+// up (convT 4x4/s2, cin -> cmid) followed by the 1x1 conv over cat[up, skip] (cmid + cskip -> cout), composed in
+// double precision: wc [cin][cout][4][4] = W1a . WT, bc = b1 + W1a . bT, and w1 (the 1x1 weights, [cout][cmid+cskip])
+static int compose_up(ldm_module* m, const std::string& up, const std::string& conv, int cin, int cmid, int cskip,
+                      int cout, std::vector<float>* wc, std::vector<float>* bc, const std::vector<float>** w1_out) {
+    const std::vector<float>*wt, *bt, *w1, *b1;
+    LDM_TRY(get_param(m, pjoin(up, "weight"), (size_t)cin * cmid * 16, &wt));
+    LDM_TRY(get_param(m, pjoin(up, "bias"), cmid, &bt));
+    LDM_TRY(get_param(m, pjoin(conv, "weight"), (size_t)cout * (cmid + cskip), &w1));
+    LDM_TRY(get_param(m, pjoin(conv, "bias"), cout, &b1));
+    const int c1 = cmid + cskip;
+    *w1_out = w1;
+    auto hit = m->composed.find(up);
+    if (hit != m->composed.end()) { *wc = hit->second.first; *bc = hit->second.second; return LDM_OK; }
+    wc->assign((size_t)cin * cout * 16, 0.f);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int k = 0; k < 16; ++k) {
+                double acc = 0.0;
+                for (int mm = 0; mm < cmid; ++mm)
+                    acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*wt)[((size_t)ci * cmid + mm) * 16 + k];
+                (*wc)[((size_t)ci * cout + co) * 16 + k] = (float)acc;
+            }
+    bc->assign(cout, 0.f);
+    for (int co = 0; co < cout; ++co) {
+        double acc = (*b1)[co];
+        for (int mm = 0; mm < cmid; ++mm) acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*bt)[mm];
+        (*bc)[co] = (float)acc;
+    }
+    m->composed[up] = std::make_pair(*wc, *bc);
+    return LDM_OK;
+}
+
 // up (convT 4x4/s2, cin -> cmid) followed by the 1x1 conv over cat[up, skip] (cmid + cskip -> cout), as one
 // transposed conv over the sources {x, skip}: the 1x1 conv is linear, so
 //   out = (W1a . WT) (*) x + W1b . skip + (b1 + W1a . bT)
@@ -416,27 +453,10 @@ static int pack_conv1x1_cat(ldm_module* m, const std::string& name, int cin0, in
 // the output pixel itself: its chunks have a single tap.
 static int pack_up_fused(ldm_module* m, const std::string& up, const std::string& conv, int cin, int cmid, int cskip,
                          int cout, PackedConv* pc) {
-    const std::vector<float>*wt, *bt, *w1, *b1;
-    LDM_TRY(get_param(m, pjoin(up, "weight"), (size_t)cin * cmid * 16, &wt));
-    LDM_TRY(get_param(m, pjoin(up, "bias"), cmid, &bt));
-    LDM_TRY(get_param(m, pjoin(conv, "weight"), (size_t)cout * (cmid + cskip), &w1));
-    LDM_TRY(get_param(m, pjoin(conv, "bias"), cout, &b1));
+    std::vector<float> wc, bc;
+    const std::vector<float>* w1;
+    LDM_TRY(compose_up(m, up, conv, cin, cmid, cskip, cout, &wc, &bc, &w1));
     const int c1 = cmid + cskip;
-    std::vector<float> wc((size_t)cin * cout * 16);     // [ci][co][ky][kx]
-    for (int ci = 0; ci < cin; ++ci)
-        for (int co = 0; co < cout; ++co)
-            for (int k = 0; k < 16; ++k) {
-                double acc = 0.0;
-                for (int mm = 0; mm < cmid; ++mm)
-                    acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*wt)[((size_t)ci * cmid + mm) * 16 + k];
-                wc[((size_t)ci * cout + co) * 16 + k] = (float)acc;
-            }
-    std::vector<float> bc(cout);
-    for (int co = 0; co < cout; ++co) {
-        double acc = (*b1)[co];
-        for (int mm = 0; mm < cmid; ++mm) acc += (double)(*w1)[(size_t)co * c1 + mm] * (double)(*bt)[mm];
-        bc[co] = (float)acc;
-    }
     PackSpec sp;
     sp.kind = CONVT4x4_S2;
     sp.dtype = m->dtype;
@@ -521,6 +541,64 @@ static int pack_dense_layer(ldm_module* m, int kind, const std::string& name, co
     return pack_conv(sp, m->pool, pc, nullptr);
 }
 
+// The same composition between whole images (see Dense4): x is a Hin x Hin image, skip and the output 2Hin x 2Hin.
+// Row (pixel, channel) of x, then of skip -> column (output pixel, channel); the skip part is block diagonal.
+static int pack_dense_up_fused(ldm_module* m, const std::string& up, const std::string& conv, int Hin, int cin, int cmid,
+                               int cskip, int cout, PackedConv* pc) {
+    std::vector<float> wc, bc;
+    const std::vector<float>* w1;
+    LDM_TRY(compose_up(m, up, conv, cin, cmid, cskip, cout, &wc, &bc, &w1));
+    const int c1 = cmid + cskip, Win = Hin, Wout = 2 * Hin, Pin = Hin * Hin, Pout = 4 * Pin;
+    PackSpec sp;
+    sp.kind = CONV1x1;
+    sp.dtype = m->dtype;
+    sp.cout = Pout * cout;
+    sp.src = {Pin * cin, Pout * cskip};
+    sp.w = [&](int, int, int n, int k) {
+        const int po = n / cout, co = n % cout;
+        if (k >= Pin * cin) {
+            const int ps = (k - Pin * cin) / cskip, cs = (k - Pin * cin) % cskip;
+            return ps == po ? (*w1)[(size_t)co * c1 + cmid + cs] : 0.f;
+        }
+        const int pi = k / cin, ci = k % cin;
+        const int ky = po / Wout - 2 * (pi / Win) + 1, kx = po % Wout - 2 * (pi % Win) + 1;
+        if (ky < 0 || ky >= 4 || kx < 0 || kx >= 4) return 0.f;
+        return wc[((size_t)ci * cout + co) * 16 + ky * 4 + kx];
+    };
+    sp.bias = [&](int n) { return bc[n % cout]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
+// Attention with one token per image: soft-max over a single key is 1, so Attention::forward (src/main.rs:256-276)
+// is out(val(x)) + x; the two Linears composed in double precision (the residual stays in the epilogue).
+static int pack_attention_one_token(ldm_module* m, const std::string& prefix, int C, PackedConv* pc) {
+    const std::vector<float>*wv, *bv, *wo, *bo;
+    LDM_TRY(get_param(m, pjoin(prefix, "val.weight"), (size_t)C * C, &wv));
+    LDM_TRY(get_param(m, pjoin(prefix, "val.bias"), C, &bv));
+    LDM_TRY(get_param(m, pjoin(prefix, "out.weight"), (size_t)C * C, &wo));
+    LDM_TRY(get_param(m, pjoin(prefix, "out.bias"), C, &bo));
+    std::vector<float> w((size_t)C * C), b(C);     // Linear weights are [d_in, d_out]
+    for (int ci = 0; ci < C; ++ci)
+        for (int co = 0; co < C; ++co) {
+            double acc = 0.0;
+            for (int mm = 0; mm < C; ++mm) acc += (double)(*wv)[(size_t)ci * C + mm] * (double)(*wo)[(size_t)mm * C + co];
+            w[(size_t)ci * C + co] = (float)acc;
+        }
+    for (int co = 0; co < C; ++co) {
+        double acc = (*bo)[co];
+        for (int mm = 0; mm < C; ++mm) acc += (double)(*bv)[mm] * (double)(*wo)[(size_t)mm * C + co];
+        b[co] = (float)acc;
+    }
+    PackSpec sp;
+    sp.kind = CONV1x1;
+    sp.dtype = m->dtype;
+    sp.cout = C;
+    sp.src = {C};
+    sp.w = [&](int, int, int co, int ci) { return w[(size_t)ci * C + co]; };
+    sp.bias = [&](int co) { return b[co]; };
+    return pack_conv(sp, m->pool, pc, nullptr);
+}
+
 // wt [te][tv] / bt [tv]: the per-block time projections side by side (block i at column m->rb[i].tv_off)
 static int pack_dense4(ldm_module* m, const std::vector<float>& wt, const std::vector<float>& bt) {
     Dense4& d = m->d4;
@@ -551,6 +629,9 @@ static int pack_dense4(ldm_module* m, const std::vector<float>& wt, const std::v
     LDM_TRY(pack_dense_layer(m, CONVT4x4_S2, "up1", "", 1, 1, c3, c3, c2, c2, &d.up1));
     LDM_TRY(pack_dense_layer(m, CONVT4x4_S2, "up2", "", 2, 2, c2, c2, c1, c1, &d.up2));
     LDM_TRY(pack_dense_layer(m, CONV3x3_S1, "out_conv", "", 4, 4, c1, c1, cl, m->clp, &d.out_conv));
+    LDM_TRY(pack_dense_up_fused(m, "up1", "up_conv1", 1, c3, c2, c2, c2, &d.up1c));
+    LDM_TRY(pack_dense_up_fused(m, "up2", "up_conv2", 2, c2, c1, c1, c1, &d.up2c));
+    LDM_TRY(pack_attention_one_token(m, "mid_atten", c3, &d.att1));
     d.ready = true;
     return LDM_OK;
 }
@@ -692,6 +773,7 @@ static int finalize_module(ldm_module* m) {
         LDM_TRY(pack_dense4(m, wt, bt));
     }
     m->params.clear();
+    m->composed.clear();
     m->finalized = true;
     return LDM_OK;
 }
@@ -870,18 +952,30 @@ static int run_unet_dense4(const ldm_module* m, UnetBufs& ub, const void* xin, v
     LDM_TRY(mat(d.down3, ub.s2, ub.a3, ACT_NONE, nullptr, -1, 0));
     LDM_TRY(block(2, ub.a3, ub.b3, ub.c3));
     LDM_TRY(block(3, ub.c3, ub.b3, ub.a3));
-    LDM_TRY(atten(m->mid_atten, 1, ub.a3, ub.qkv3, ub.att3, ub.b3));
+    // Up to this many images a launch costs more than its FLOPs: consecutive linear layers run composed (the block-
+    // diagonal skip part of the composed up-sampling matrices multiplies 4 / 16 times the FLOPs of up_conv1/2).
+    const bool composed = Bp <= 256;
+    if (composed) LDM_TRY(mat(d.att1, ub.a3, ub.b3, ACT_NONE, ub.a3, -1, 0));
+    else LDM_TRY(atten(m->mid_atten, 1, ub.a3, ub.qkv3, ub.att3, ub.b3));
     LDM_TRY(block(4, ub.b3, ub.c3, ub.a3));
-    LDM_TRY(mat(d.up1, ub.a3, ub.a2, ACT_NONE, nullptr, -1, 0));
-    LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, 1, R * 4, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (composed) {
+        LDM_TRY(run_conv(d.up1c, ub.a3, c3, ub.s2, 4 * c2, ub.b2, 1, R, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    } else {
+        LDM_TRY(mat(d.up1, ub.a3, ub.a2, ACT_NONE, nullptr, -1, 0));
+        LDM_TRY(run_conv(m->up_conv1, ub.a2, c2, ub.s2, c2, ub.b2, 1, R * 4, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    }
     LDM_TRY(block(5, ub.b2, ub.a2, ub.s2));
     const void* u1 = ub.s2;
     if (m->scaled) {
         LDM_TRY(atten(m->up_atten, 4, ub.s2, ub.qkv2, ub.att2, ub.b2));
         u1 = ub.b2;
     }
-    LDM_TRY(mat(d.up2, u1, ub.a1, ACT_NONE, nullptr, -1, 0));
-    LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, 1, R * 16, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (composed) {
+        LDM_TRY(run_conv(d.up2c, u1, 4 * c2, ub.s1, 16 * c1, ub.b1, 1, R, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    } else {
+        LDM_TRY(mat(d.up2, u1, ub.a1, ACT_NONE, nullptr, -1, 0));
+        LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, 1, R * 16, 16, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    }
     LDM_TRY(block(6, ub.b1, ub.a1, ub.s1));
     (void)c3;
     return mat(d.out_conv, ub.s1, eps_out, ACT_NONE, nullptr, -1, 1);
