@@ -539,11 +539,8 @@ static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStrea
     constexpr size_t stage = (size_t)2 * 32 * D * 2;
     constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage;
     auto kern = attention_stream_kernel<D, QF, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+    LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     dim3 grid((unsigned)(N / QB), (unsigned)B);
@@ -559,11 +556,8 @@ static int launch_attn_cfg(const void* qkv, void* out, int B, int N, hipStream_t
     const size_t lds = (size_t)4 * TILE;
     static_assert(4 * TILE <= 160 * 1024, "LDS budget");
     auto kern = attention_kernel<T, D, QF, KF, MINB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+    LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     dim3 grid((unsigned)((N + QB - 1) / QB), (unsigned)B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);

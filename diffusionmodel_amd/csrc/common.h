@@ -39,6 +39,20 @@ void set_error(const std::string& msg);
         if (r_ != LDM_OK) return r_; \
     } while (0)
 
+// Dynamic LDS above the default limit is an attribute of the kernel on ONE device: it is set the first time a
+// kernel is launched on each device of the process.  `done` is the caller's static flag array for that kernel.
+constexpr int kMaxDevices = 64;
+inline int allow_dynamic_lds(const void* kernel, int bytes, bool (&done)[kMaxDevices]) {
+    int dev = 0;
+    LDM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) LDM_FAIL(LDM_ERR_INVALID, "device index out of range");
+    if (!done[dev]) {
+        LDM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done[dev] = true;
+    }
+    return LDM_OK;
+}
+
 // f32 -> bf16 round-to-nearest-even on the host (NaN kept quiet).
 inline bf16_t host_f2bf(float f) {
     uint32_t u;

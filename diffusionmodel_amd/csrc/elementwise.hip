@@ -632,12 +632,9 @@ int launch_linear_bf16(const float* in, const void* wp, const float* b, void* ou
         LDM_HIP(hipGetDevice(&dev));
         LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LDM_HIP(hipFuncSetAttribute((const void*)linear_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool lds_set16[kMaxDevices] = {}, lds_set4[kMaxDevices] = {};   // per kernel and device
+    LDM_TRY(allow_dynamic_lds((const void*)linear_bf16_kernel<16>, 160 * 1024, lds_set16));
+    LDM_TRY(allow_dynamic_lds((const void*)linear_bf16_kernel<4>, 160 * 1024, lds_set4));
     const size_t lds = (size_t)64 * K * 2;
     int grid = N / 64;
     if (grid > ncu) grid = ncu;

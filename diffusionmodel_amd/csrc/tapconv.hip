@@ -1611,11 +1611,8 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     a.nblk_n = a.cout / BN;
     if (a.ntaps != NTAPS) LDM_FAIL(LDM_ERR_INVALID, "tap count does not match the kernel");
     auto kern = tapconv_kernel<T, TH, BN, WM, WN, S, KEXT, NTAPS, MINW, RING, NT1>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+    LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     a.nphase = nphase;
     dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8 * a.nblk_n * nphase), 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, stream, a);
@@ -1682,11 +1679,8 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
         a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            LDM_HIP(hipFuncSetAttribute((const void*)s2ws_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+        LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<2, 1>, 160 * 1024, lds_set));
         const size_t lds = 2 * 2 * 6 * 4096;             // two windows of two chunks
         const int ncb = a.cout / 64;                     // one workgroup per CU, the CUs split over the channel blocks
         int per = ncu / ncb;
@@ -1855,11 +1849,8 @@ int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* o
     a.tiles_x = Win / 16; a.tiles_y = Hin / 4; a.ntiles = a.tiles_x * a.tiles_y * B;
     a.w_phase_stride = (long)9 * 64 * 128;           // 2 chunks x 4 taps + 1 skip slab of 8 KiB per phase
     const size_t lds = 2 * 64 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDM_HIP(hipFuncSetAttribute((const void*)upfuse_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+    LDM_TRY(allow_dynamic_lds((const void*)upfuse_ws_kernel, 160 * 1024, lds_set));
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     hipLaunchKernelGGL(upfuse_ws_kernel, dim3(grid), dim3(512), lds, stream, a);
     LDM_HIP(hipGetLastError());
