@@ -176,8 +176,6 @@ struct SchedArgs {
     unsigned long long seed;
     unsigned int chain0;   // global index of the first chain held by this process
     const unsigned int* rng;   // optional device words {seed low, seed high, chain0}: override the two above
-    int* advance;          // optional: the workgroup that finishes last writes step + 1 to this word (normally step_ptr)
-    int* ticket;           // its workgroup counter, 0 between launches (required with `advance`)
 };
 // ctl[0] = 0 (step counter), ctl[1..3] = {seed low, seed high, chain0}, ctl[4] = 0 (workgroup ticket of the fused update)
 int launch_set_ctl(int* ctl, unsigned long long seed, unsigned int chain0, hipStream_t s);

@@ -120,17 +120,6 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const SchedArgs a) {
             *(uint2*)((char*)a.z_lowp + i * 8) = w;
         }
     }
-    if (a.advance) {
-        // every workgroup read the step counter before it took a ticket, so the last ticket may move the counter
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) {
-                *a.ticket = 0;
-                *a.advance = step + 1;
-            }
-        }
-    }
 }
 
 // Forward process q(x_t | x_0), DiffusionModel::add_noise (src/main.rs:584-630):
@@ -206,7 +195,6 @@ int launch_sched_step(const SchedArgs& a, hipStream_t s) {
     LDM_REQUIRE(a.n > 0 && a.pix_per_chain > 0 && a.c4 > 0 && a.cpad4 >= a.c4 &&
                     a.n % (a.pix_per_chain * a.cpad4 * 4) == 0,
                 "element count must be a whole number of chains");
-    LDM_REQUIRE(!a.advance || a.ticket, "advancing the step counter needs the ticket word");
     hipLaunchKernelGGL(sched_step_kernel, dim3(ew_grid(a.n / 4)), dim3(256), 0, s, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;

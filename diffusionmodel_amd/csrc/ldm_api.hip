@@ -1061,9 +1061,9 @@ static int sampler_step(ldm_sampler* s, int mode, bool have_noise, unsigned long
     a.c4 = m->in_ch / 4; a.cpad4 = m->clp / 4;
     a.seed = seed; a.chain0 = chain0;
     a.rng = (const unsigned int*)(s->step + 1);   // device copy, so a captured graph follows later seeds
-    a.advance = s->step;                          // the update's last workgroup also moves the step counter
-    a.ticket = s->step + 4;
-    return launch_sched_step(a, st);
+    LDM_TRY(launch_sched_step(a, st));
+    LDM_TRY(launch_step_advance(s->step, st));
+    return LDM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
