@@ -246,3 +246,27 @@ def test_noise_predict_at_4x4_with_a_time_per_image(A, O, dtype, B):
     _say(f"noise_predict 4x4 {dtype} B={B}: vs tap kernels rel={e_tap:.3e}, vs oracle rel={e_ref:.3e}")
     assert e_tap < (2e-5 if dtype == "fp32" else 2e-2) and e_ref < TOL[dtype]
     assert e_tap > 0 or dtype == "fp32"       # the two paths really are different code
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_4x4_path_with_a_narrow_latent(A, O, dtype):
+    """8 latent channels (padded to 64 inside): the whole-image matrices keep the padded columns zero, and the
+    sampler's epsilon agrees with the oracle and with the tap kernels."""
+    cfg = A.LDMConfig(8, 256, (64, 128, 256), False)
+    w = A.make_synthetic_weights(cfg, 21)
+    B, steps = 6, 3
+    z0 = torch.randn(B, 8, 4, 4, generator=torch.Generator().manual_seed(5))
+    m = _model(A, dtype, 1000, w, cfg)
+    _say(f"narrow latent 4x4 {dtype}")
+    got_z, zt, et = m.ddim_sample(B, steps, spatial=4, z0=z0.cuda(), use_graph=False, return_trace=True)
+    torch.cuda.synchronize()
+    assert tuple(got_z.shape) == (B, 8, 4, 4) and torch.isfinite(got_z).all()
+    ts = m.ddim_timesteps(steps)
+    for k in range(steps):
+        temb = O.sin_time_addition(torch.full((B,), int(ts[k])), 256)
+        ref = O.unet_forward(w, zt[k].cpu(), temb)
+        with _tap_kernels_at_4x4():
+            tap = m.noise_predict(zt[k], temb.cuda())
+            torch.cuda.synchronize()
+        assert rel_err(et[k], ref) < TOL[dtype]
+        assert rel_err(et[k], tap) < (2e-5 if dtype == "fp32" else 2e-2)
