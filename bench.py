@@ -9,8 +9,8 @@ With N > 1 ranks every rank denoises its own 64 chains (weak scaling) and one al
 the final latents inside the timed region.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline     -- the dominant kernel (3x3 tap convolution 64->64 channels on [64,64,64,64]) timed
-                  alone with HIP events on the launch stream: algorithmic FLOPs / average duration
+  roofline     -- the dominant kernel (3x3 tap convolution 256->256 channels on [64,16,16,256], six launches
+                  per UNet step) timed alone with HIP events on the launch stream: algorithmic FLOPs / average duration
                   against the dense bf16 MFMA peak of 2.5 PFLOP/s;
   cpu_baseline -- the CPU restatement of the reference's Rust path (oracle/, torch CPU f32) timed on
                   the host cores on a bounded sample (rank 0, N = 1 only).
@@ -220,6 +220,8 @@ def main():
         kms, kflop = time_dominant_kernel(A, args.dtype, B, s_dom, c_dom)
         achieved = kflop / (kms * 1e-3) / 1e12
         kname = f"tapconv 3x3 {c_dom}->{c_dom} on [{B},{s_dom},{s_dom},{c_dom}] {args.dtype}"
+        if S == 4:   # non-default run: at 4x4 latents the sampler runs whole-image matrices, not this kernel
+            kname += " (tap kernel timed for reference; the 4x4 sampler uses the matrix path)"
         levels = {}
         for lv, (cc, ss) in enumerate(((cfg.channels[0], S), (cfg.channels[1], S // 2))):
             ms_l, fl_l = time_dominant_kernel(A, args.dtype, B, ss, cc)
