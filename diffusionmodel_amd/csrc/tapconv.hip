@@ -73,6 +73,9 @@
 #ifndef TAPCONV_S2WS_128
 #define TAPCONV_S2WS_128 1
 #endif
+#ifndef SKINNY3_MAXWG_F32
+#define SKINNY3_MAXWG_F32 1024       // f32 3x3 convolutions with at most this many skinny workgroups take the skinny kernel
+#endif
 #ifndef TAPCONV_SKINNY_MAXM
 #define TAPCONV_SKINNY_MAXM 512      // 1x1 convolutions over at most this many pixels take the skinny kernel
 #endif
@@ -1578,6 +1581,122 @@ __global__ __launch_bounds__(64 * NWV) void skinny1x1_kernel(const TapConvArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same idea for 3x3 convolutions (stride 1 or 2, padding 1) over few pixels: single images or small
+// batches, where the tiled kernel's launch is a handful of workgroups that each walk all (chunk, tap) steps
+// behind a barrier (9 us per launch whatever the batch, from 1 to 16 images of 64x64).  A workgroup owns 16
+// output channels of a 4x16-pixel tile; its waves split the (chunk, tap) pairs; a lane reads its pixel's
+// neighbour for the tap straight from global memory (the zero page outside the image), the weights from
+// the pair's slab of the packed layout.  Partial sums meet in LDS; epilogue as in the tiled kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int S, int NWV>
+__global__ __launch_bounds__(64 * NWV) void skinny3x3_kernel(const TapConvArgs a) {
+    constexpr int MF = 4;
+    __shared__ __attribute__((aligned(16))) float part[NWV * MF * 16 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int tile = blockIdx.y;
+    const int img = tile / (a.tiles_x * a.tiles_y);
+    const int trem = tile - img * (a.tiles_x * a.tiles_y);
+    const int y0 = (trem / a.tiles_x) * MF, x0 = (trem % a.tiles_x) * 16;
+    const size_t slab = (size_t)a.cout * 128, plane = (size_t)a.cout * 32;
+    const char* zero = (const char*)g_zero16;
+    const char* in_img = a.in0 + (size_t)img * a.Hin * a.Win * a.cin0_bytes;
+
+    // epilogue operands first (see skinny1x1_kernel): thread -> pixel (y0 + tid/64, x0 + (tid/4)%16), 4 channels
+    const int pl = tid >> 2, cg = tid & 3;
+    const int ey = y0 + (pl >> 4), ex = x0 + (pl & 15);
+    const bool mine = pl < MF * 16 && ey < a.Hout && ex < a.Wout;
+    const int co = n0 + cg * 4;
+    const size_t eo = (((size_t)img * a.Hout + (mine ? ey : 0)) * a.Wout + (mine ? ex : 0)) * a.cout + co;
+    const f32x4 bias = *(const f32x4*)(a.bias + co);
+    f32x4 resv = {0.f, 0.f, 0.f, 0.f}, tv = {0.f, 0.f, 0.f, 0.f};
+    if (a.res) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 r = *(const uint2*)(a.res + eo * 2);
+            resv[0] = bf2f((bf16_t)(r.x & 0xffffu)); resv[1] = bf2f((bf16_t)(r.x >> 16));
+            resv[2] = bf2f((bf16_t)(r.y & 0xffffu)); resv[3] = bf2f((bf16_t)(r.y >> 16));
+        } else {
+            resv = *(const f32x4*)(a.res + eo * 4);
+        }
+    }
+    if (a.tvec) {
+        const int step = a.step_ptr ? *a.step_ptr : 0;
+        tv = *(const f32x4*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co);
+    }
+
+    f32x4 acc[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* wl = a.w + (size_t)(g >> 1) * plane + (size_t)(n0 + l15) * 32 + (g & 1) * 16;
+    const int npairs = a.nch0 * 9;
+    const int ox = x0 + l15;
+    // One (chunk, tap) pair per iteration: its ten fragment loads go out together and the wave waits for them
+    // once.  (Loading the next pair ahead of the MFMAs was measured slower: the loads that run past a wave's last
+    // pair cost more than the overlap gains at 1-5 pairs per wave.)
+    for (int q = wave; q < npairs; q += NWV) {
+        const int c = q / 9, t = q - c * 9;
+        const int dy = t / 3, dx = t - dy * 3;
+        const int ix = ox * S + dx - 1;
+        const bool xok = ox < a.Wout && (unsigned)ix < (unsigned)a.Win;
+        const char* src[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int oy = y0 + mf, iy = oy * S + dy - 1;
+            const bool ok = xok && oy < a.Hout && (unsigned)iy < (unsigned)a.Hin;
+            src[mf] = ok ? in_img + ((size_t)iy * a.Win + ix) * a.cin0_bytes + (size_t)c * 128 + g * 16 : zero;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const u32x4 wf = *(const u32x4*)(wl + (size_t)q * slab + (size_t)kk * 2 * plane);
+            u32x4 xf[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) xf[mf] = *(const u32x4*)(src[mf] + (src[mf] == zero ? 0 : kk * 64));
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
+                                                                      __builtin_bit_cast(bf16x8, xf[mf]), acc[mf], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2f(wf[e]), u2f(xf[mf][e]), acc[mf], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) *(f32x4*)(part + ((wave * MF * 16 + mf * 16 + l15) * 16 + g * 4)) = acc[mf];
+    __syncthreads();
+    if (!mine) return;
+    f32x4 v = *(const f32x4*)(part + (pl * 16 + cg * 4));
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += *(const f32x4*)(part + ((w * MF * 16 + pl) * 16 + cg * 4));
+    v += bias;
+    v += resv;
+    if (a.act == ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f<sizeof(T) == 4>(v[e]);
+    } else if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (a.act == ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    }
+    v += tv;
+    if (sizeof(T) == 4 || a.out_f32) {
+        *(f32x4*)(a.out + eo * 4) = v;
+    } else {
+        uint2 o;
+        o.x = pack2(v[0], v[1]);
+        o.y = pack2(v[2], v[3]);
+        *(uint2*)(a.out + eo * 2) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
@@ -1733,6 +1852,19 @@ static int launch_skinny1x1(TapConvArgs& a, hipStream_t stream) {
 }
 
 template <typename T>
+static int launch_skinny3x3(const PackedConv& pc, TapConvArgs& a, hipStream_t stream) {
+    constexpr int NWV = sizeof(T) == 2 ? 8 : 16;
+    a.tiles_x = (a.Wout + 15) / 16;
+    a.tiles_y = (a.Hout + 3) / 4;
+    a.ntiles = a.tiles_x * a.tiles_y * a.B;
+    const dim3 grid((unsigned)(a.cout / 16), (unsigned)a.ntiles), block(64 * NWV);
+    if (pc.kind == CONV3x3_S1) hipLaunchKernelGGL((skinny3x3_kernel<T, 1, NWV>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((skinny3x3_kernel<T, 2, NWV>), grid, block, 0, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+template <typename T>
 static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a, hipStream_t stream) {
     int bn = (a.cout % 128 == 0) ? 128 : 64;
     {
@@ -1754,6 +1886,15 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         }
     }
     if (a.sched_z) LDM_FAIL(LDM_ERR_INVALID, "the fused DDIM update needs the 64-channel bf16 kernel (see tapconv_can_fuse_ddim)");
+    if ((pc.kind == CONV3x3_S1 || pc.kind == CONV3x3_S2) && a.nch1 == 0) {
+        // f32, a few images: the tiled kernel walks 18-72 (chunk, tap) steps per workgroup behind barriers.  Measured
+        // on 50-step DDPM, 4 latents of 64x64, f32: 95 -> 124 images/s.  In bf16 (half the steps) the tiled kernel
+        // is as fast at one image and faster from four on, so bf16 takes this kernel only when LDM_SKINNY3_MAXWG says so.
+        static long maxwg = -1;
+        if (maxwg < 0) { const char* e = getenv("LDM_SKINNY3_MAXWG"); maxwg = e ? atol(e) : (sizeof(T) == 4 ? SKINNY3_MAXWG_F32 : 0); }
+        const long t64 = (long)((a.Wout + 15) / 16) * ((a.Hout + 3) / 4) * a.B;
+        if (t64 <= 65535 && t64 * (a.cout / 16) <= maxwg) return launch_skinny3x3<T>(pc, a, stream);
+    }
     // measured at 1024 -> 1024 channels: 145 vs 206 us per sampler step at 256 pixels, a tie at 1024, half the speed at 4096
     if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= TAPCONV_SKINNY_MAXM) return launch_skinny1x1<T>(a, stream);
     if constexpr (sizeof(T) == 2) {

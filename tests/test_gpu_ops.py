@@ -243,6 +243,35 @@ def test_conv_stride2_large(A, B, S, cin, cout):
     assert e < 4e-3      # bf16 rounding of the output only
 
 
+# ---- f32 3x3 convolutions over a few images: the skinny 3x3 kernel --------------------------------
+@pytest.mark.parametrize("stride,B,S,cin,cout,act,res", [(1, 1, 16, 256, 256, "silu", True), (1, 2, 22, 64, 64, None, False),
+                                                         (1, 3, 7, 128, 128, "relu", True), (2, 1, 32, 128, 256, None, False),
+                                                         (2, 2, 14, 64, 128, None, False), (1, 16, 64, 64, 64, None, False)])
+def test_conv3x3_f32_small_batches(A, stride, B, S, cin, cout, act, res):
+    """f32 conv3x3 (stride 1 and 2, padding 1; src/main.rs:348-366, 434-452) at one to three images, ragged against
+    the 4x16-pixel tile, with and without activation and residual, against torch f32; the last case is large enough
+    for the tiled kernel (the same operator, the other kernel)."""
+    import torch.nn.functional as F
+    from diffusionmodel_amd.ops import ConvOp, from_nhwc, to_nhwc
+    g = torch.Generator().manual_seed(B * 100 + S + cout + stride)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * cin ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, S, S, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, generator=g)
+        ref = ref + r.double()
+    ref = F.silu(ref) if act == "silu" else F.relu(ref) if act == "relu" else ref
+    _say(f"conv3x3 f32 stride={stride} B={B} S={S} {cin}->{cout} act={act} res={res}")
+    op = ConvOp("conv3x3" if stride == 1 else "conv3x3_s2", w, b, dtype="fp32")
+    got = from_nhwc(op(to_nhwc(x, "fp32").cuda(), None, res=None if r is None else to_nhwc(r, "fp32").cuda(), act=act))
+    torch.cuda.synchronize()
+    e = rel_err(got, ref.float())
+    _say(f"  rel_err={e:.3e}")
+    assert e < 1e-5
+
+
 # ---- forward process and loss value ---------------------------------------------------------------
 def test_add_noise_bit_exact(A, O):
     T, B = 1000, 6
