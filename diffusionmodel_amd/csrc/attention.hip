@@ -587,7 +587,10 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
         switch (C) {
             case 64: return launch_attn_cfg<float, 64, 2, 2>(qkv, out, B, N, stream);
             case 128: return launch_attn_cfg<float, 128, 2, 2>(qkv, out, B, N, stream);
-            case 256: return launch_attn_cfg<float, 256, 2, 1>(qkv, out, B, N, stream);
+            case 256:
+                // few images: 64 queries per workgroup instead of 128 doubles the workgroups (8 -> 16 at 4 images of 256 tokens)
+                if ((long)B * ((N + 127) / 128) < 256) return launch_attn_cfg<float, 256, 1, 1>(qkv, out, B, N, stream);
+                return launch_attn_cfg<float, 256, 2, 1>(qkv, out, B, N, stream);
             case 512: return launch_attn_cfg<float, 512, 1, 1>(qkv, out, B, N, stream);
         }
     }
