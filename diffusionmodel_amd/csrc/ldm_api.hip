@@ -917,7 +917,7 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
 
 // Unet::forward for Bp = 16*R images of 4x4 latents through the matrices of Dense4: every buffer [Bp, P*C] is
 // handed to the tap kernel as ONE image of R x 16 pixels with P*C channels (spatial layers) or of R*P x 16 pixels
-// with C channels (per-pixel layers).  All images share the time vector (tv.img_stride is not used).
+// with C channels (per-pixel layers).  tv.pix_stride = 0: all images share the time vector; otherwise one row per image.
 static int run_unet_dense4(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int Bp, const TimeVec& tv,
                            hipStream_t st) {
     const Dense4& d = m->d4;

@@ -1474,8 +1474,8 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
 // 1x1 convolution over a few pixels (a Linear over a handful of rows): the sampler at the reference's own
 // sizes, batch 1-4 of 4x4 latents, where every layer is such a product and the run time is the latency of
 // streaming the weights.  The tiled kernel gives a problem like that cout/64 workgroups, each walking all
-// input chunks with a barrier per chunk.  Here a workgroup owns 16 output channels of up to 64 pixels, its 8 or 16 waves split the
-// input chunks, and every fragment comes straight from global memory into registers (weights in the packed
+// input chunks with a barrier per chunk.  Here a workgroup owns 16 output channels of up to 64 pixels, its 8 or
+// 16 waves split the input chunks, and every fragment comes straight from global memory into registers (weights in the packed
 // layout: chunk slab, pair plane, row; activations: the 16-byte piece kk*4 + g of the pixel's chunk), so all
 // loads of a wave are in flight at once; the partial sums meet in LDS.  Epilogue as in the tiled kernel.
 // ---------------------------------------------------------------------------------------------
