@@ -568,11 +568,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         f32x4 v0 = *(const f32x4*)(smem + p * RS + cg * 32) + b0;
         f32x4 v1 = *(const f32x4*)(smem + p * RS + cg * 32 + 16) + b1;
         if (a.res) { v0 += r0[i]; v1 += r1[i]; }
-        if (a.t_pix_stride) {      // a time vector per pixel (uniform branch; rare)
-            const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
-            const float* tp = tv + (size_t)((gy < a.Hg ? gy : a.Hg - 1) * a.Wg + (gx < a.Wg ? gx : a.Wg - 1)) * a.t_pix_stride;
-            t0 = *(const f32x4*)tp;
-            t1 = *(const f32x4*)(tp + 4);
+        if constexpr (NTAPS == 1) {     // 1x1 convolutions only (the 3x3 instantiations stay as they were)
+            if (a.t_pix_stride) {       // a time vector per pixel: a batch handed over as one image
+                const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+                const float* tp = tv + (size_t)((gy < a.Hg ? gy : a.Hg - 1) * a.Wg + (gx < a.Wg ? gx : a.Wg - 1)) * a.t_pix_stride;
+                t0 = *(const f32x4*)tp;
+                t1 = *(const f32x4*)(tp + 4);
+            }
         }
         if (a.act == ACT_SILU) {
 #pragma unroll
