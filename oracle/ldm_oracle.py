@@ -107,16 +107,26 @@ def residual_block(p, prefix: str, x, t_emb):
 # --------------------------------------------------------------------------------------------
 # a8  Attention                                                      src/main.rs:256-276
 # --------------------------------------------------------------------------------------------
-def attention(p, prefix: str, x):
+def attention(p, prefix: str, x, q_chunk: int = 2048):
+    """q_chunk only bounds host memory: the [tokens, tokens] score matrix is built `q_chunk` query rows at a
+    time.  Every row still sees all keys, so each soft-max is the exact one of src/main.rs:267-269."""
     a, b, c, d = x.shape
     xf = x.reshape(a, b, c * d).transpose(1, 2)          # [B, tokens, C]
     q = linear(p, prefix + ".question", xf)
     k = linear(p, prefix + ".key", xf)
     v = linear(p, prefix + ".val", xf)
     scaling = math.sqrt(float(b))                        # sqrt(channels)
-    score = q @ k.transpose(1, 2) / scaling
-    w = torch.softmax(score, dim=2)                      # over keys
-    o = w @ v
+    n = c * d
+    if n <= q_chunk:
+        score = q @ k.transpose(1, 2) / scaling
+        w = torch.softmax(score, dim=2)                  # over keys
+        o = w @ v
+    else:
+        o = torch.empty_like(q)
+        kt = k.transpose(1, 2)
+        for q0 in range(0, n, q_chunk):
+            score = q[:, q0:q0 + q_chunk] @ kt / scaling
+            o[:, q0:q0 + q_chunk] = torch.softmax(score, dim=2) @ v
     o = linear(p, prefix + ".out", o)
     o = o.transpose(1, 2).reshape(a, b, c, d)
     return o + x

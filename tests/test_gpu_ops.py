@@ -117,6 +117,29 @@ def test_attention(A, O, dtype, C, B, H, W):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+# The token counts the scaled UNet sees at 256x256 latents: 16 384 tokens at 256 channels (its second attention) and
+# 4 096 tokens at 512 channels (the innermost one).  bf16 with enough images for 256 workgroups takes the long-sequence
+# kernels that run there (8 waves sharing every key/value tile: four-stage ring at 256 channels, two-stage ring at 512);
+# one image takes the four-wave kernel; f32 takes the f32 kernel.  The oracle builds the score matrix 2 048 query rows
+# at a time (exact soft-max per row).
+@pytest.mark.parametrize("dtype,C,B,H,W", [("bf16", 256, 4, 128, 128), ("bf16", 256, 1, 128, 128), ("fp32", 256, 1, 128, 128),
+                                            ("bf16", 512, 8, 64, 64), ("bf16", 512, 1, 64, 64), ("fp32", 512, 1, 64, 64)])
+def test_attention_at_the_scaled_unet_token_counts(A, O, dtype, C, B, H, W):
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    w = synthetic_from_shapes(attention_param_shapes(C), 5)
+    torch.manual_seed(C + B)
+    x = torch.randn(B, C, H, W) * 2.0
+    _say(f"attention {dtype} C={C} {B}x{H}x{W} ({H * W} tokens)")
+    ref = O.attention({"m." + k: v for k, v in w.items()}, "m", x)
+    got = A.Attention(C, dtype=dtype, weights=w)(x.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    e_branch = rel_err(got - x.cuda(), ref - x)
+    _say(f"  rel_err={e:.3e} branch={e_branch:.3e}")
+    assert e < TOL[dtype]
+    assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
+
+
 @pytest.mark.parametrize("spike_at", [5, 600, 1023])
 def test_attention_running_max_jump_long_sequence(A, O, spike_at):
     """The same property on the long-sequence kernel (bf16, 1024 tokens, 64 images)."""
@@ -422,6 +445,55 @@ def test_unet_scaled(A, O, dtype):
     e = rel_err(got, ref)
     _say(f"  rel_err={e:.3e}")
     assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype,B,S", [("fp32", 1, 64), ("bf16", 1, 64), ("bf16", 2, 128)])
+def test_unet_scaled_larger_latents(A, O, dtype, B, S):
+    """The scaled UNet (channels 128/256/512, second attention after up_res1) against the oracle at 64x64 latents
+    (1 024 and 256 tokens) and at 128x128 (4 096 and 1 024 tokens)."""
+    cfg = A.LDMConfig.scaled()
+    w = A.make_synthetic_weights(cfg, 0)
+    torch.manual_seed(40 + S)
+    x = torch.randn(B, 64, S, S)
+    te = O.sin_time_addition(torch.tensor([900, 120][:B]), 256)
+    _say(f"unet scaled {dtype} B={B} S={S}")
+    ref = O.unet_forward(w, x, te, scaled_attention=True)
+    net = A.UNet(64, 256, channels=cfg.channels, scaled_attention=True, dtype=dtype, weights=w)
+    got = net(x.cuda(), te.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert e < TOL[dtype]
+
+
+def test_unet_scaled_full_size_properties(A):
+    """Scaled UNet at 256x256 latents, bf16, four images (16 384- and 4 096-token attention on the long-sequence
+    kernels): finite; the whole batch equals its two halves (which take other attention kernels: another summation
+    order, nothing else); a DDIM loop replayed from its graph equals the eager loop bit for bit, twice."""
+    cfg = A.LDMConfig.scaled()
+    w = A.make_synthetic_weights(cfg, 0)
+    g = torch.Generator().manual_seed(256)
+    x = torch.randn(4, 64, 256, 256, generator=g).cuda()
+    te = A.sin_time_addition(torch.tensor([999, 500, 20, 0]).cuda(), 256)
+    _say("unet scaled 256x256 bf16: batch slices")
+    net = A.UNet(64, 256, channels=cfg.channels, scaled_attention=True, dtype="bf16", weights=w)
+    whole = net(x, te)
+    parts = torch.cat([net(x[i:i + 2].contiguous(), te[i:i + 2].contiguous()) for i in (0, 2)])
+    torch.cuda.synchronize()
+    e = rel_err(whole, parts)
+    _say(f"  whole batch vs halves: rel_err={e:.3e}")
+    assert torch.isfinite(whole).all()
+    assert e < 1e-2
+    del net
+    _say("unet scaled 256x256 bf16: graph vs eager")
+    m = A.DiffusionModel(64, 3, 1000, 256, cfg.channels, True, dtype="bf16", weights=w)
+    eager = m.ddim_sample(4, 3, spatial=256, z0=x, use_graph=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eager).all()
+    for _ in range(2):
+        zg = m.ddim_sample(4, 3, spatial=256, z0=x, use_graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(zg, eager)
 
 
 # ---- full benchmark size: properties that need no CPU reference ------------------------------------

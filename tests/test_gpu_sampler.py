@@ -48,9 +48,9 @@ def test_ddpm_chain_with_injected_noise(A, O, dtype):
     efin = rel_err(got_z, ref_z)
     _say(f"ddpm {dtype}: eps[0] rel={e0:.3e} final z rel={efin:.3e} psnr={psnr(got_z, ref_z):.1f} dB")
     assert e0 < TOL[dtype]
-    assert efin < (1e-4 if dtype == "fp32" else 5e-2)
-    # final samples: PSNR against the restatement (measured 150 dB in f32, 76 dB in bf16)
-    assert psnr(got_z, ref_z) > (100.0 if dtype == "fp32" else 50.0)
+    # bounds about ten times what is measured on MI355X (f32: 2.1e-7, 150.7 dB; bf16: 1.1e-3, 76.5 dB)
+    assert efin < (3e-6 if dtype == "fp32" else 1e-2)
+    assert psnr(got_z, ref_z) > (130.0 if dtype == "fp32" else 60.0)
     # teacher forcing: per-step epsilon on the oracle's own z_t
     worst = 0.0
     for k in range(T):
@@ -59,7 +59,7 @@ def test_ddpm_chain_with_injected_noise(A, O, dtype):
         e = rel_err(m.noise_predict(ref_zs[k].cuda(), temb), ref_eps[k])
         worst = max(worst, e)
     _say(f"ddpm {dtype}: worst teacher-forced eps rel={worst:.3e}")
-    assert worst < TOL[dtype]
+    assert worst < (1e-5 if dtype == "fp32" else TOL[dtype])      # measured 9.0e-7 / 5.5e-3
     # graph replay gives the same chain as eager launches, twice
     for _ in range(2):
         zg = m.denoising_process(B, spatial=S, z0=z0.cuda(), noise=noise.cuda(), use_graph=True)
@@ -80,12 +80,88 @@ def test_ddim_chain(A, O, dtype):
     efin = rel_err(got_z, ref_z)
     _say(f"ddim {dtype}: eps[0] rel={e0:.3e} final rel={efin:.3e} psnr={psnr(got_z, ref_z):.1f} dB")
     assert e0 < TOL[dtype]
-    assert efin < (1e-3 if dtype == "fp32" else 0.2)
-    assert psnr(got_z, ref_z) > (100.0 if dtype == "fp32" else 40.0)    # measured 146 dB / 65 dB
+    # measured on MI355X: f32 4.2e-7 / 145.9 dB, bf16 4.8e-3 / 64.7 dB; the bounds are about ten times that
+    assert efin < (5e-6 if dtype == "fp32" else 4e-2)
+    assert psnr(got_z, ref_z) > (125.0 if dtype == "fp32" else 50.0)
     zg = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
     zg2 = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
     torch.cuda.synchronize()
     assert torch.equal(zg, got_z) and torch.equal(zg2, got_z)
+
+
+@pytest.mark.parametrize("mode,dtype", [("ddim", "bf16"), ("ddpm", "fp32")])
+def test_benchmark_shape_chain_teacher_forced(A, O, mode, dtype):
+    """Per-step epsilon on identical latents and timesteps at the benchmark's latent shape [4,64,64,64]: the oracle
+    runs the whole 50-step chain (DDIM over 1000 timesteps in bf16 mode, DDPM over 50 with injected noise in f32
+    mode), the GPU predicts the noise for every one of the oracle's z_t (teacher forcing), and a free-running GPU
+    chain from the same start gives the final-sample PSNR.
+
+    With synthetic (untrained) weights the network is no denoiser and the DDIM chain, which like the reference never
+    clips x0, grows from rms 1 to rms 4e3.  On those latents the f32 oracle itself moves by 1.4e-2 .. 2.3e-2 when only
+    its operands (weights and z_t) are rounded to bf16, so the 2e-2 bar cannot hold there for any bf16 implementation.
+    The bar is therefore applied where that floor is below 1e-2 (the first ten steps here); elsewhere the GPU may be
+    at most twice the floor (measured: at most 1.8 times)."""
+    B, S, steps = 4, 64, 50
+    T = 1000 if mode == "ddim" else 50
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    z0 = torch.randn(B, 64, S, S, generator=torch.Generator().manual_seed(1234))
+    noise = torch.randn(T, B, 64, S, S, generator=torch.Generator().manual_seed(4321)) if mode == "ddpm" else None
+    _say(f"benchmark-shape {mode} {dtype}: oracle chain")
+    ref_z, ref_zs, ref_eps = O.denoising_process(w, z0, T, noise=noise, mode=mode, ddim_steps=steps, trace=True)
+    ts = O.ddim_timesteps(T, steps) if mode == "ddim" else list(range(T - 1, -1, -1))
+    m = _model(A, dtype, T, w)
+    w_rounded = {k: v.bfloat16().float() for k, v in w.items()} if dtype == "bf16" else None
+    worst, worst_k, worst_ratio, strict = 0.0, -1, 0.0, 0
+    for k, t in enumerate(ts):
+        temb = O.sin_time_addition(torch.full((B,), t), 256)
+        e = rel_err(m.noise_predict(ref_zs[k].cuda(), temb.cuda()), ref_eps[k])
+        if e > worst:
+            worst, worst_k = e, k
+        if dtype == "bf16":
+            floor = rel_err(O.unet_forward(w_rounded, ref_zs[k].bfloat16().float(), temb), ref_eps[k])
+            if floor < 1e-2:
+                strict += 1
+                assert e < TOL[dtype], (k, t, e, floor)
+            else:
+                worst_ratio = max(worst_ratio, e / floor)
+                assert e < 2.0 * floor, (k, t, e, floor)
+        else:
+            assert e < TOL[dtype], (k, t, e)
+    _say(f"benchmark-shape {mode} {dtype}: worst teacher-forced eps rel={worst:.3e} at step {worst_k}"
+         + (f"; {strict} steps under the 2e-2 bar, elsewhere at most {worst_ratio:.2f} x the operand-rounding floor"
+            if dtype == "bf16" else ""))
+    assert dtype != "bf16" or strict >= 8
+    if mode == "ddim":
+        got = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
+    else:
+        got = m.denoising_process(B, spatial=S, z0=z0.cuda(), noise=noise.cuda(), use_graph=True)
+    torch.cuda.synchronize()
+    efin, p = rel_err(got, ref_z), psnr(got, ref_z)
+    _say(f"benchmark-shape {mode} {dtype}: free-running final rel={efin:.3e} psnr={p:.1f} dB")
+    assert torch.isfinite(got).all()
+    # measured: f32 2.4e-7 / 153 dB, bf16 1.05e-2 / 57.5 dB
+    assert efin < (3e-6 if dtype == "fp32" else 0.1) and p > (130.0 if dtype == "fp32" else 40.0)
+
+
+def test_benchmark_shape_epsilon_on_forward_process_latents(A, O):
+    """The strict bf16 bar at the benchmark's latent shape on latents that look like what a trained model sees:
+    z_t = sqrt(abar_t) x0 + sqrt(1 - abar_t) n (unit variance at every timestep), all 50 DDIM timesteps, the GPU and the
+    oracle on identical z_t and t."""
+    B, S, steps, T = 4, 64, 50, 1000
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    g = torch.Generator().manual_seed(99)
+    x0 = torch.randn(B, 64, S, S, generator=g)
+    abar = O.get_alphas(T)
+    m = _model(A, "bf16", T, w)
+    worst = 0.0
+    for t in O.ddim_timesteps(T, steps):
+        n = torch.randn(B, 64, S, S, generator=g)
+        z = x0 * float(abar[t]) ** 0.5 + n * float(1.0 - abar[t]) ** 0.5
+        temb = O.sin_time_addition(torch.full((B,), t), 256)
+        e = rel_err(m.noise_predict(z.cuda(), temb.cuda()), O.unet_forward(w, z, temb))
+        worst = max(worst, e)
+        assert e < TOL["bf16"], (t, e)
+    _say(f"benchmark-shape forward-process latents bf16: worst eps rel={worst:.3e} over {steps} timesteps")
 
 
 def test_builtin_generator_chain_matches_oracle_and_is_shard_invariant(A, O):
@@ -101,7 +177,7 @@ def test_builtin_generator_chain_matches_oracle_and_is_shard_invariant(A, O):
     torch.cuda.synchronize()
     e = rel_err(got, ref)
     _say(f"philox chain rel={e:.3e}")
-    assert e < 1e-3
+    assert e < 3e-6                 # measured 1.6e-7
     # two "ranks" of 2 chains each, different seed afterwards must change the result (graph reuse)
     parts = [m.denoising_process(2, spatial=S, seed=seed, chain0=c0, use_graph=True) for c0 in (0, 2)]
     torch.cuda.synchronize()
@@ -124,7 +200,7 @@ def test_long_chain_fp32_drift(A, O):
     e = rel_err(got, ref)
     _say(f"1000-step ddpm fp32 rel={e:.3e} |z|max={ref.abs().max().item():.3e}")
     assert torch.isfinite(got).all()
-    assert e < 1e-2
+    assert e < 5e-6                 # measured 4.4e-7
 
 
 def test_ddim_fused_update_large_latent(A, O):
@@ -144,7 +220,7 @@ def test_ddim_fused_update_large_latent(A, O):
     # Two bf16 chains differ from each other about as much as each differs from the f32 oracle (measured:
     # 1.1e-2 / 1.2e-2 / 1.2e-2): the first DDIM step divides by sqrt(abar_750) and every later UNet call
     # re-rounds the state to bf16, so different f32 summation orders decorrelate the roundings.
-    assert e_pair < 5e-2 and e_ref < 5e-2 and e_ref_u < 5e-2
+    assert e_pair < 3e-2 and e_ref < 3e-2 and e_ref_u < 3e-2
     for _ in range(2):            # graph replays: the same chain, the step counter restarts every call
         zg = m.ddim_sample(B, steps, spatial=S, z0=z0.cuda(), use_graph=True)
         torch.cuda.synchronize()

@@ -216,3 +216,15 @@ def test_host_add_noise_coefficients_match_oracle():
     from diffusionmodel_amd import schedule
     for T in (50, 1000):
         assert np.array_equal(schedule.add_noise_coefficients(T), O.add_noise_coefficients(T))
+
+
+def test_attention_query_chunks_do_not_change_the_result():
+    """The oracle builds the score matrix a block of query rows at a time for long sequences; every row still sees
+    all keys, so the result is the unchunked one (up to the summation order of the matrix products)."""
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    w = {"m." + k: v for k, v in synthetic_from_shapes(attention_param_shapes(64), 5).items()}
+    x = torch.randn(2, 64, 12, 10, generator=torch.Generator().manual_seed(1)) * 2.0
+    whole = O.attention(w, "m", x, q_chunk=4096)
+    for chunk in (7, 32, 119):
+        part = O.attention(w, "m", x, q_chunk=chunk)
+        assert (part - whole).abs().max().item() < 1e-5
