@@ -53,6 +53,21 @@ inline int allow_dynamic_lds(const void* kernel, int bytes, bool (&done)[kMaxDev
     return LDM_OK;
 }
 
+// Compute units of the current device (cached per device: a process may drive different parts).
+inline int device_cu_count(int* out) {
+    static int cus[kMaxDevices] = {};        // 0 = not asked yet; racing first calls store the same value
+    int dev = 0;
+    LDM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) LDM_FAIL(LDM_ERR_INVALID, "device index out of range");
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (n == 0) {
+        LDM_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    *out = n;
+    return LDM_OK;
+}
+
 // f32 -> bf16 round-to-nearest-even on the host (NaN kept quiet).
 inline bf16_t host_f2bf(float f) {
     uint32_t u;
@@ -122,6 +137,9 @@ int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* o
 
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
+// Name of the kernel the calling thread's last launch_tapconv / launch_upfuse started, spelled as a profiler lists it
+// ("void ldm::tapconv_kernel<unsigned short, 16, 64, 4, 2, 1, 3, 9, 2, 3, 9>(ldm::TapConvArgs)"); "" before the first.
+const char* tapconv_last_kernel();
 
 // ---------------------------------------------------------------------------------------------
 // Attention core: softmax(q k^T / sqrt(C)) v over the tokens of one image, single head.
@@ -158,6 +176,8 @@ int launch_add_noise(const float* x, const float* noise, const int* t, const flo
                      long per_sample, hipStream_t s);
 // out[0] = mean((a - b)^2) over n elements; partial_ws: 1024 floats of device scratch
 int launch_mse(const float* a, const float* b, long n, float* partial_ws, float* out, hipStream_t s);
+// *flag = 1 if all n elements of z are finite, else 0 (two launches: a fill and the probe)
+int launch_finite_check(const float* z, long n, int* flag, hipStream_t s);
 // sinusoidal embedding of integer timesteps (src/main.rs:309-335)
 int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s);
 

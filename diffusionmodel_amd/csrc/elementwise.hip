@@ -183,6 +183,23 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = red[0] / (float)n;
 }
 
+// Finiteness probe of a latent (the checks of src/main.rs:780-784, 788-792 on the mean: a mean is NaN or infinite
+// as soon as one element is).  *flag is preset to 1 by a fill kernel; any wave that sees an element with an all-ones
+// exponent stores 0 (every writer stores the same value).
+__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ z, long n, int* __restrict__ flag) {
+    bool bad = false;
+    const long n4 = n / 4;
+    const f32x4* z4 = (const f32x4*)z;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = z4[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bad |= (__builtin_bit_cast(unsigned int, (float)v[q]) & 0x7f800000u) == 0x7f800000u;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        bad |= (__builtin_bit_cast(unsigned int, z[i]) & 0x7f800000u) == 0x7f800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 0;
+}
+
 static inline int ew_grid(long work_items) {
     long g = (work_items + 255) / 256;
     if (g > 2048) g = 2048;
@@ -614,12 +631,8 @@ int launch_linear_bf16(const float* in, const void* wp, const float* b, void* ou
     LDM_REQUIRE(in && wp && out && rows > 0, "bad arguments");
     LDM_REQUIRE(K > 0 && K % 128 == 0 && K <= 1024 && N > 0 && N % 16 == 0, "Linear shape not served (K multiple of 128 up to 1024, N multiple of 16)");
     LDM_REQUIRE(act == ACT_NONE || act == ACT_RELU, "activation not served by the wide Linear");
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        LDM_HIP(hipGetDevice(&dev));
-        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    LDM_TRY(device_cu_count(&ncu));
     static bool lds_set16[kMaxDevices] = {}, lds_set4[kMaxDevices] = {};   // per kernel and device
     LDM_TRY(allow_dynamic_lds((const void*)linear_bf16_kernel<16>, 160 * 1024, lds_set16));
     LDM_TRY(allow_dynamic_lds((const void*)linear_bf16_kernel<4>, 160 * 1024, lds_set4));
@@ -673,6 +686,15 @@ int launch_mse(const float* a, const float* b, long n, float* partial_ws, float*
     LDM_REQUIRE(a && b && partial_ws && out && n > 0, "bad arguments");
     hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, s, a, b, n, partial_ws);
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, n, out);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+int launch_finite_check(const float* z, long n, int* flag, hipStream_t s) {
+    LDM_REQUIRE(z && flag && n > 0, "bad arguments");
+    LDM_REQUIRE(((uintptr_t)z & 15) == 0, "the tensor must be 16-byte aligned");
+    LDM_TRY(launch_set_int(flag, 1, s));
+    hipLaunchKernelGGL(finite_check_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, z, n, flag);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

@@ -1022,6 +1022,7 @@ struct ldm_sampler {
     int g_steps = -1, g_noise = -1, g_mode = -1;
     std::vector<float> h_coef;
     std::vector<int> h_ts;
+    int up_mode = -1, up_steps = -1;   // (mode, steps) whose tables are in device memory
     ~ldm_sampler() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -1126,6 +1127,12 @@ int ldm_add_noise(const float* x, const float* noise, const int* t, const float*
 int ldm_mse(const float* a, const float* b, long n, float* ws1024, float* out, void* stream) {
     return launch_mse(a, b, n, ws1024, out, (hipStream_t)stream);
 }
+
+int ldm_latent_is_finite(const float* z, long n, int* flag, void* stream) {
+    return launch_finite_check(z, n, flag, (hipStream_t)stream);
+}
+
+const char* ldm_last_kernel(void) { return tapconv_last_kernel(); }
 
 int ldm_sin_time_addition(const int* time_dev, int batch, int dim, float* out_dev, void* stream) {
     return launch_sin_embed(time_dev, batch, dim, out_dev, (hipStream_t)stream);
@@ -1397,28 +1404,37 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
     ldm_module* m = s->unet;
     hipStream_t st = (hipStream_t)stream;
     const int B = s->B, H = s->H, W = s->W, T = s->T;
-    int steps = T;
-    std::vector<float> c5;
-    if (mode == LDM_DDPM) {
-        host_ddpm_coef(T, c5);
-        s->h_ts.resize(T);
-        s->h_coef.assign((size_t)T * 8, 0.f);
-        for (int k = 0; k < T; ++k) {
-            const int i = T - 1 - k;
-            s->h_ts[k] = i;
-            for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)i * 5 + q];
-            s->h_coef[(size_t)k * 8 + 5] = 0.f;
-            s->h_coef[(size_t)k * 8 + 6] = i == 0 ? 1.f : 0.f;
+    const int steps = mode == LDM_DDPM ? T : ddim_steps;
+    // The timestep and coefficient tables depend on (mode, steps) only: they are built and uploaded when those change
+    // (a synchronous copy, so the host vectors are free again when it returns), not on every call.
+    if (s->up_mode != mode || s->up_steps != steps) {
+        std::vector<float> c5;
+        if (mode == LDM_DDPM) {
+            host_ddpm_coef(T, c5);
+            s->h_ts.resize(T);
+            s->h_coef.assign((size_t)T * 8, 0.f);
+            for (int k = 0; k < T; ++k) {
+                const int i = T - 1 - k;
+                s->h_ts[k] = i;
+                for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)i * 5 + q];
+                s->h_coef[(size_t)k * 8 + 5] = 0.f;
+                s->h_coef[(size_t)k * 8 + 6] = i == 0 ? 1.f : 0.f;
+            }
+        } else {
+            LDM_TRY(host_ddim_ts(T, steps, s->h_ts));
+            LDM_TRY(host_ddim_coef(T, steps, c5));
+            s->h_coef.assign((size_t)steps * 8, 0.f);
+            for (int k = 0; k < steps; ++k) {
+                for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)k * 5 + q];
+                s->h_coef[(size_t)k * 8 + 5] = 1.f;
+            }
         }
-    } else {
-        steps = ddim_steps;
-        LDM_TRY(host_ddim_ts(T, steps, s->h_ts));
-        LDM_TRY(host_ddim_coef(T, steps, c5));
-        s->h_coef.assign((size_t)steps * 8, 0.f);
-        for (int k = 0; k < steps; ++k) {
-            for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)k * 5 + q];
-            s->h_coef[(size_t)k * 8 + 5] = 1.f;
-        }
+        s->up_mode = s->up_steps = -1;
+        // work of earlier calls may still read the old tables
+        LDM_HIP(hipDeviceSynchronize());
+        LDM_HIP(hipMemcpy(s->d_ts, s->h_ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice));
+        LDM_HIP(hipMemcpy(s->coef, s->h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice));
+        s->up_mode = mode; s->up_steps = steps;
     }
     const bool have_noise = noise_dev != nullptr && mode == LDM_DDPM;
     const size_t nz = (size_t)B * H * W * m->clp;
@@ -1433,8 +1449,6 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
             if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
         }
     }
-    LDM_HIP(hipMemcpyAsync(s->d_ts, s->h_ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice, st));
-    LDM_HIP(hipMemcpyAsync(s->coef, s->h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice, st));
     // time path for every visited timestep at once: [steps, tv_total] table (all chains share t)
     LDM_TRY(launch_sin_embed(s->d_ts, steps, m->te, s->ub.sinemb, st));
     LDM_TRY(run_time_path(m, s->ub.sinemb, steps, s->ub, st, s->dense4));

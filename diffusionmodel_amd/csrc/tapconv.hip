@@ -38,6 +38,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 // Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
@@ -1701,6 +1702,11 @@ __global__ __launch_bounds__(64 * NWV) void skinny3x3_kernel(const TapConvArgs a
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static thread_local const char* g_last_kernel = "";
+const char* tapconv_last_kernel() { return g_last_kernel; }
+
+template <typename T> static const char* type_name() { return sizeof(T) == 2 ? "unsigned short" : "float"; }
+
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout) {
     switch (kind) {
         case CONV3x3_S1:
@@ -1735,6 +1741,11 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
     LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     a.nphase = nphase;
+    static const std::string name = std::string("void ldm::tapconv_kernel<") + type_name<T>() + ", " + std::to_string(TH) + ", " +
+        std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " + std::to_string(S) + ", " +
+        std::to_string(KEXT) + ", " + std::to_string(NTAPS) + ", " + std::to_string(MINW) + ", " + std::to_string(RING) + ", " +
+        std::to_string(NT1) + ">(ldm::TapConvArgs)";
+    g_last_kernel = name.c_str();
     dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8 * a.nblk_n * nphase), 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, stream, a);
     LDM_HIP(hipGetLastError());
@@ -1751,18 +1762,16 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
 
 template <int MODE>
 static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        LDM_HIP(hipGetDevice(&dev));
-        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    LDM_TRY(device_cu_count(&ncu));
     a.tiles_x = a.Wg / 16;
     a.tiles_y = a.Hg / 8;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     a.nblk_n = 1;
     const size_t lds = 2 * 6 * 4096 + 4 * 4 * 1024;  // two halo buffers of 10x18 pixels + staged epilogue inputs
     const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+    static const std::string name = "void ldm::tapconv_ws64_kernel<" + std::to_string(MODE) + ">(ldm::TapConvArgs)";
+    g_last_kernel = name.c_str();
     hipLaunchKernelGGL(tapconv_ws64_kernel<MODE>, dim3(grid), dim3(256), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
@@ -1786,18 +1795,15 @@ static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
            a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
 }
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        LDM_HIP(hipGetDevice(&dev));
-        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    LDM_TRY(device_cu_count(&ncu));
     a.tiles_x = a.Wout / 16;
     a.tiles_y = a.Hout / 2;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     if (a.nch0 == 1) {
         const size_t lds = 2 * 6 * 4096;                 // two windows of 5 x 33 pixels
         a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+        g_last_kernel = "void ldm::s2ws_kernel<1, 2>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
     } else {
         static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
@@ -1808,6 +1814,7 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
         if (per < 1) per = 1;
         if (per > a.ntiles) per = a.ntiles;
         a.nblk_n = per;
+        g_last_kernel = "void ldm::s2ws_kernel<2, 1>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<2, 1>), dim3(per * ncb), dim3(256), lds, stream, a);
     }
     LDM_HIP(hipGetLastError());
@@ -1822,18 +1829,15 @@ static bool ws1x1_shape(const PackedConv& pc, const TapConvArgs& a) {
 
 template <bool RES>
 static int launch_ws1x1(TapConvArgs& a, hipStream_t stream) {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        LDM_HIP(hipGetDevice(&dev));
-        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    LDM_TRY(device_cu_count(&ncu));
     const int ncb = a.cout / 256;
     a.ntiles = (int)((long)a.B * a.Hin * a.Win / 32);
     int per = 2 * ncu / ncb;                       // workgroups per block of 256 output channels
     if (per > a.ntiles) per = a.ntiles;
     a.nblk_n = per;
     const size_t lds = 2 * 16 * 1024;              // two tiles of 32 pixels x 512 bytes
+    g_last_kernel = RES ? "void ldm::ws1x1_kernel<true>(ldm::TapConvArgs)" : "void ldm::ws1x1_kernel<false>(ldm::TapConvArgs)";
     hipLaunchKernelGGL(ws1x1_kernel<RES>, dim3((unsigned)(per * ncb)), dim3(256), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
@@ -1846,6 +1850,7 @@ static int launch_skinny1x1(TapConvArgs& a, hipStream_t stream) {
     // 4 / 8 / 16 waves; f32, twice the chunks, 6.0 / 4.6 / 4.3 us)
     constexpr int NWV = sizeof(T) == 2 ? 8 : 16;
     const dim3 block(64 * NWV);
+    g_last_kernel = "ldm::skinny1x1_kernel";
     if (M <= 16) hipLaunchKernelGGL((skinny1x1_kernel<T, 1, NWV>), dim3((unsigned)(a.cout / 16), 1), block, 0, stream, a);
     else if (M <= 32) hipLaunchKernelGGL((skinny1x1_kernel<T, 2, NWV>), dim3((unsigned)(a.cout / 16), 1), block, 0, stream, a);
     else hipLaunchKernelGGL((skinny1x1_kernel<T, 4, NWV>), dim3((unsigned)(a.cout / 16), (unsigned)((M + 63) / 64)), block, 0, stream, a);
@@ -1860,6 +1865,7 @@ static int launch_skinny3x3(const PackedConv& pc, TapConvArgs& a, hipStream_t st
     a.tiles_y = (a.Hout + 3) / 4;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
     const dim3 grid((unsigned)(a.cout / 16), (unsigned)a.ntiles), block(64 * NWV);
+    g_last_kernel = "ldm::skinny3x3_kernel";
     if (pc.kind == CONV3x3_S1) hipLaunchKernelGGL((skinny3x3_kernel<T, 1, NWV>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((skinny3x3_kernel<T, 2, NWV>), grid, block, 0, stream, a);
     LDM_HIP(hipGetLastError());
@@ -1892,8 +1898,10 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         // f32, a few images: the tiled kernel walks 18-72 (chunk, tap) steps per workgroup behind barriers.  Measured
         // on 50-step DDPM, 4 latents of 64x64, f32: 95 -> 124 images/s.  In bf16 (half the steps) the tiled kernel
         // is as fast at one image and faster from four on, so bf16 takes this kernel only when LDM_SKINNY3_MAXWG says so.
-        static long maxwg = -1;
-        if (maxwg < 0) { const char* e = getenv("LDM_SKINNY3_MAXWG"); maxwg = e ? atol(e) : (sizeof(T) == 4 ? SKINNY3_MAXWG_F32 : 0); }
+        static const long maxwg = [] {       // read once per process (and element type)
+            const char* e = getenv("LDM_SKINNY3_MAXWG");
+            return e ? atol(e) : (long)(sizeof(T) == 4 ? SKINNY3_MAXWG_F32 : 0);
+        }();
         const long t64 = (long)((a.Wout + 15) / 16) * ((a.Hout + 3) / 4) * a.B;
         if (t64 <= 65535 && t64 * (a.cout / 16) <= maxwg) return launch_skinny3x3<T>(pc, a, stream);
     }
@@ -1980,12 +1988,8 @@ int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* o
     LDM_REQUIRE(x && skip && out && pc.w && pc.bias, "null tensor");
     LDM_REQUIRE(pc.kind == CONVT4x4_S2 && pc.cin == 192 && pc.ntaps1 == 1 && upfuse_shape_ok(pc.dtype, 128, 64, pc.cout, B, Hin, Win),
                 "shape not served by the fused up-sampling kernel");
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        LDM_HIP(hipGetDevice(&dev));
-        LDM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    LDM_TRY(device_cu_count(&ncu));
     TapConvArgs a{};
     a.in0 = (const char*)x; a.in1 = (const char*)skip; a.w = (const char*)pc.w; a.bias = pc.bias; a.out = (char*)out;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = 2 * Hin; a.Wout = 2 * Win; a.cout = 64;
@@ -1995,6 +1999,7 @@ int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* o
     static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
     LDM_TRY(allow_dynamic_lds((const void*)upfuse_ws_kernel, 160 * 1024, lds_set));
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    g_last_kernel = "ldm::upfuse_ws_kernel(ldm::TapConvArgs)";
     hipLaunchKernelGGL(upfuse_ws_kernel, dim3(grid), dim3(512), lds, stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;

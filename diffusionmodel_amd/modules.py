@@ -232,6 +232,16 @@ def sched_step(z: torch.Tensor, eps: torch.Tensor, coef5, mode: str = "ddpm", la
     return z
 
 
+def latent_is_finite(t: torch.Tensor) -> bool:
+    """The reference's probe `mean().is_nan() || mean().is_infinite()` (src/main.rs:780-781, 788-789, 647-648) as one
+    reduction over the elements on the device: True when every element of `t` is finite.  Reads one flag back (the
+    host synchronisation the reference has at the same place)."""
+    t = _dev_f32(t, "t")
+    flag = torch.empty(1, dtype=torch.int32, device=t.device)
+    _lib.check(_lib.load().ldm_latent_is_finite(_ptr(t), t.numel(), _ptr(flag), _stream()))
+    return bool(flag.item())
+
+
 def philox_normal(batch: int, channels: int, H: int, W: int, seed: int, chain0: int = 0, step: int = 0xFFFFFFFF,
                   device="cuda") -> torch.Tensor:
     """The Gaussian field the sampler's built-in generator draws at `step` (0xFFFFFFFF: initial latent)."""
@@ -312,21 +322,30 @@ class DiffusionModel:
         return out, noise
 
     def forward(self, z: torch.Tensor, time: Optional[torch.Tensor] = None,
-                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                noise: Optional[torch.Tensor] = None, check_finite: bool = False) -> torch.Tensor:
         """The loss value of DiffusionModel::forward (src/main.rs:635-679) from the latent on: random
         timesteps (or `time`), add_noise, sinusoidal embedding, noise prediction, mean squared error.
         z is what the reference obtains from vae.encode(x).detach() (:636; the encoder stays with the
-        reference).  Returns a tensor of shape [1].  Value only: there is no backward pass here."""
+        reference).  Returns a tensor of shape [1].  Value only: there is no backward pass here.
+        check_finite: the reference's three probes (:647-651, 657-662, 672-676): a noisy latent, a prediction or a
+        loss that is not finite gives the sentinel loss 100.0 (each probe reads a flag back, as the reference's do)."""
         z = _dev_f32(z, "z")
         B = z.shape[0]
         if time is None:
             time = torch.randint(0, self.num_time, (B,), device=z.device)
         z_noisy, noise = self.add_noise(z, time, noise)
+        sentinel = lambda: torch.full((1,), 100.0, dtype=torch.float32, device=z.device)   # noqa: E731
+        if check_finite and not latent_is_finite(z_noisy):
+            return sentinel()
         t_emb = sin_time_addition(time.to(z.device), self.time_embed_dim)
         pred = self.noise_predict(z_noisy, t_emb)
+        if check_finite and not latent_is_finite(pred):
+            return sentinel()
         ws = torch.empty(1024, dtype=torch.float32, device=z.device)
-        out = torch.empty(1, dtype=torch.float32, device=z.device)
+        out = torch.empty(4, dtype=torch.float32, device=z.device)[:1]     # 16-byte aligned for the probe
         _lib.check(self._lib.ldm_mse(_ptr(pred), _ptr(noise), pred.numel(), _ptr(ws), _ptr(out), _stream()))
+        if check_finite and not latent_is_finite(out):
+            return sentinel()
         return out
 
     def decode(self, z: torch.Tensor) -> torch.Tensor:
@@ -335,11 +354,16 @@ class DiffusionModel:
             raise RuntimeError("this DiffusionModel was built without decoder_weights")
         return self.decoder.forward(z)
 
-    def sample_images(self, batch_size: int, **kw) -> torch.Tensor:
+    def sample_images(self, batch_size: int, check_finite: bool = False, **kw) -> torch.Tensor:
         """denoising_process followed by vae.decode, as the reference's denoising_process returns
-        (src/main.rs:681-795): [B, in_channels, 64, 64] in [-1, 1]."""
+        (src/main.rs:681-795): [B, in_channels, 64, 64] in [-1, 1].  check_finite: the reference's two probes after
+        the loop: a latent that is not finite is replaced by zeros before decoding (:780-784), a decoded image that
+        is not finite by zeros (:788-792)."""
         kw.pop("return_trace", None)
-        return self.decode(self.denoising_process(batch_size, spatial=4, **kw))
+        img = self.decode(self.denoising_process(batch_size, spatial=4, check_finite=check_finite, **kw))
+        if check_finite and not latent_is_finite(img):
+            img.zero_()
+        return img
 
     # -- sampling -------------------------------------------------------------------------------
     def _sampler(self, B: int, H: int, W: int) -> C.c_void_p:
@@ -351,7 +375,7 @@ class DiffusionModel:
         return self._samplers[key]
 
     def _run(self, mode: int, steps: int, batch_size: int, spatial, z0, noise, seed: int, chain0: int, use_graph: bool,
-             return_trace: bool):
+             return_trace: bool, check_finite: bool = False):
         H, W = (spatial, spatial) if isinstance(spatial, int) else spatial
         Cl = self.latent_dimen
         if z0 is not None:
@@ -368,22 +392,28 @@ class DiffusionModel:
         _lib.check(self._lib.ldm_sampler_run(h, mode, steps, _ptr(z0), _ptr(noise), seed & (2 ** 64 - 1),
                                              chain0 & 0xFFFFFFFF, _ptr(out), _ptr(zt), _ptr(et), int(use_graph),
                                              _stream()))
+        if check_finite and not latent_is_finite(out):     # src/main.rs:780-784: the fallback tensor is all zeros
+            out.zero_()
         if return_trace:
             return out, zt, et
         return out
 
     def denoising_process(self, batch_size: int, spatial=4, z0: Optional[torch.Tensor] = None,
                           noise: Optional[torch.Tensor] = None, seed: int = 0, chain0: int = 0,
-                          use_graph: bool = True, return_trace: bool = False):
+                          use_graph: bool = True, return_trace: bool = False, check_finite: bool = False):
         """DDPM ancestral sampling, i = num_time-1 .. 0 (src/main.rs:681-777).
 
         spatial: latent height/width (the reference hard-codes 4x4, :683).  z0 / noise: optional
         injected initial latent [B,C,H,W] and per-step noise [num_time,B,C,H,W]; otherwise the built-in
-        counter-based generator is used with (seed, chain0)."""
+        counter-based generator is used with (seed, chain0).  check_finite: the reference's probe after the loop
+        (:780-784): a final latent that is not finite is replaced by zeros (one flag is read back; the per-step
+        probes of the reference are not reproduced)."""
         return self._run(_lib.LDM_DDPM, self.num_time, batch_size, spatial, z0, noise, seed, chain0, use_graph,
-                         return_trace)
+                         return_trace, check_finite)
 
     def ddim_sample(self, batch_size: int, steps: int = 50, spatial=4, z0: Optional[torch.Tensor] = None,
-                    seed: int = 0, chain0: int = 0, use_graph: bool = True, return_trace: bool = False):
+                    seed: int = 0, chain0: int = 0, use_graph: bool = True, return_trace: bool = False,
+                    check_finite: bool = False):
         """Deterministic DDIM (eta = 0) over `steps` strided timesteps; not part of the reference."""
-        return self._run(_lib.LDM_DDIM, steps, batch_size, spatial, z0, None, seed, chain0, use_graph, return_trace)
+        return self._run(_lib.LDM_DDIM, steps, batch_size, spatial, z0, None, seed, chain0, use_graph, return_trace,
+                         check_finite)

@@ -14,7 +14,20 @@
  *  - inference semantics: BatchNorm uses running statistics (folded into the preceding conv,
  *    eps 1e-5), Dropout is the identity;
  *  - the per-step NaN probes of denoising_process (src/main.rs:706-710,725-729,759-763) are host
- *    synchronisations and are not reproduced.
+ *    synchronisations and are not reproduced; the probes after the loop (:780-784, :788-792) and those of
+ *    DiffusionModel::forward (:647-651, 657-662, 672-676) are offered as ldm_latent_is_finite, which the caller
+ *    runs after the loop (the Python surface: check_finite=True).
+ *
+ * Threads and streams: a module or sampler owns ONE set of activation buffers (a module's grows on demand, which
+ * synchronises the device and reallocates).  Calls on the same module or sampler must not overlap: one stream at a
+ * time, one host thread at a time.  Different modules and samplers are independent.
+ *
+ * Environment variables read by the library (developer switches; the defaults are what is measured and tested):
+ *   LDM_DENSE4=0           keep the tiled convolution kernels at 4x4 latents instead of the whole-image matrices.
+ *                          ldm_unet_forward reads it at every call, ldm_sampler_create once (the sampler keeps
+ *                          its choice).
+ *   LDM_SKINNY3_MAXWG=n    3x3 convolutions with at most n skinny workgroups take the skinny kernel (default: 1024
+ *                          in f32, 0 in bf16); read once per process.
  */
 #ifndef LDM_HIP_H
 #define LDM_HIP_H
@@ -126,6 +139,11 @@ int ldm_conv_create(ldm_conv** out, int kind, int dtype, int cin0, int cin1, int
 int ldm_conv_forward(ldm_conv* c, const void* in0_dev, const void* in1_dev, const void* res_dev, void* out_dev,
                      int B, int Hin, int Win, int act, void* stream);
 void ldm_conv_destroy(ldm_conv* c);
+/* Diagnostics (no counterpart in the reference): the name of the convolution kernel that the calling thread's last
+ * ldm_conv_forward (or any other convolution launch of the library) started, spelled as rocprofv3 lists it, e.g.
+ * "void ldm::tapconv_kernel<unsigned short, 16, 64, 4, 2, 1, 3, 9, 2, 3, 9>(ldm::TapConvArgs)".  bench.py uses it to
+ * pick the hardware-counter record that belongs to the kernel it timed. */
+const char* ldm_last_kernel(void);
 
 /* ---- one scheduler update on flat f32 arrays, src/main.rs:712-756,765 --------------------- */
 /* coef5 = one row of ldm_ddpm_coefficients / ldm_ddim_coefficients.  DDPM: z <- (x0*c1 + z*c2) +
@@ -136,10 +154,12 @@ int ldm_sched_step(float* z_dev, const float* eps_dev, const float* noise_dev, l
 
 /* ---- the sampling loop: DiffusionModel::denoising_process, src/main.rs:681-777 ------------ */
 /* The loop runs on `batch` independent chains of shape [in_channels,H,W]; the trailing vae.decode
- * (:786) is outside this library.  All per-call memory is allocated by ldm_sampler_create.
+ * (:786) is outside this library.  ldm_sampler_create allocates the activation buffers, the state and the tables;
+ * ldm_sampler_run allocates only when the caller injects per-step noise (noise_dev): a buffer for its NHWC copy,
+ * on first use and when more steps are asked for (that synchronises the device).  The timestep and coefficient
+ * tables are uploaded when (mode, steps) change, not per call.
  * At H = W = 4, the latent size of the reference's VAE, the sampler (and ldm_unet_forward) runs every
- * spatial layer as one matrix between whole images, built at ldm_module_finalize; the environment variable
- * LDM_DENSE4=0, read at each call, keeps the tiled convolution kernels at that size instead. */
+ * spatial layer as one matrix between whole images, built at ldm_module_finalize (LDM_DENSE4 above). */
 int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int batch, int H, int W);
 /* mode LDM_DDPM visits i = num_time-1 .. 0; LDM_DDIM visits ddim_steps strided timesteps.
  * z0_dev   [batch,C,H,W] initial latent, or NULL: drawn from the counter-based generator.
@@ -153,6 +173,14 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0_de
                     unsigned long long seed, unsigned int chain0, float* z_out_dev, float* z_trace_dev,
                     float* eps_trace_dev, int use_graph, void* stream);
 void ldm_sampler_destroy(ldm_sampler* s);
+
+/* The finiteness probes the reference runs outside its loop: on the final latent before vae.decode
+ * (src/main.rs:780-784), on the decoded image (:788-792) and on the tensors of DiffusionModel::forward
+ * (:647-651, 657-662, 672-676).  The reference reads the mean back and tests it; a mean is NaN or infinite as soon as
+ * one element is, so this probe looks at the elements: *flag_dev = 1 when all n f32 elements of z_dev are finite,
+ * 0 otherwise.  Two small launches on `stream`, no host synchronisation: the caller reads the flag when it wants
+ * to and applies the reference's fallback (zeros, or the loss value 100).  z_dev must be 16-byte aligned. */
+int ldm_latent_is_finite(const float* z_dev, long n, int* flag_dev, void* stream);
 
 /* Standard-normal field of the counter-based generator, [batch,C,H,W] f32 (C multiple of 4):
  * what ldm_sampler_run draws at `step` (0xFFFFFFFF = the initial latent). */

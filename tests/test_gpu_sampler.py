@@ -346,3 +346,41 @@ def test_4x4_path_with_a_narrow_latent(A, O, dtype):
             torch.cuda.synchronize()
         assert rel_err(et[k], ref) < TOL[dtype]
         assert rel_err(et[k], tap) < (2e-5 if dtype == "fp32" else 2e-2)
+
+
+def test_finiteness_probe_and_fallbacks(A, O):
+    """The reference's probes outside its loop (src/main.rs:780-784, 788-792, 647-676), offered as an optional
+    reduction after the loop: NaN / Inf injected into z0 propagate through the chain; check_finite=True replaces
+    the result by zeros (latent, image) or by the sentinel loss 100, as the reference does; without it they
+    propagate."""
+    _say("finiteness probe")
+    x = torch.randn(3, 64, 4, 4, generator=torch.Generator().manual_seed(1)).cuda()
+    assert A.latent_is_finite(x)
+    for bad, pos in ((float("nan"), 0), (float("inf"), 1500), (float("-inf"), x.numel() - 1)):
+        y = x.clone()
+        y.view(-1)[pos] = bad
+        assert not A.latent_is_finite(y)
+    odd = torch.randn(4099, generator=torch.Generator().manual_seed(2)).cuda()    # not a multiple of 4 elements
+    assert A.latent_is_finite(odd)
+    odd[4098] = float("nan")
+    assert not A.latent_is_finite(odd)
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    wd = A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 21)
+    m = A.DiffusionModel(64, 3, 10, 256, dtype="fp32", weights=w, decoder_weights=wd)
+    z0 = torch.randn(2, 64, 4, 4, generator=torch.Generator().manual_seed(3)).cuda()
+    good = m.denoising_process(2, spatial=4, z0=z0, seed=5, check_finite=True)
+    assert torch.equal(good, m.denoising_process(2, spatial=4, z0=z0, seed=5)) and good.abs().max().item() > 0
+    zbad = z0.clone()
+    zbad[1, 7, 2, 2] = float("nan")
+    assert not torch.isfinite(m.denoising_process(2, spatial=4, z0=zbad, seed=5)).all()
+    fallback = m.denoising_process(2, spatial=4, z0=zbad, seed=5, check_finite=True)
+    assert tuple(fallback.shape) == (2, 64, 4, 4) and (fallback == 0).all()
+    assert (m.ddim_sample(2, 5, spatial=4, z0=zbad, check_finite=True) == 0).all()
+    img = m.sample_images(2, z0=zbad, seed=5, check_finite=True)
+    # the latent fallback is all zeros, so the image is decode(0): finite, and equal to the decoder's own output
+    assert torch.isfinite(img).all() and torch.equal(img, m.decode(torch.zeros_like(z0)))
+    # loss value: sentinel 100.0 when the latent is not finite, the ordinary value otherwise
+    t = torch.tensor([1, 5]).cuda()
+    n = torch.randn(2, 64, 4, 4, generator=torch.Generator().manual_seed(4)).cuda()
+    assert m.forward(zbad, t, n, check_finite=True).item() == 100.0
+    assert torch.equal(m.forward(z0, t, n, check_finite=True), m.forward(z0, t, n))
