@@ -2,6 +2,8 @@
 // (src/main.rs:712-756,765), layout changes at the loop boundary, the sinusoidal timestep embedding
 // (src/main.rs:309-335), the tiny f32 Linears of the time path (src/main.rs:302-306,377-378) and a
 // counter-based normal generator.  All of them stream 16 bytes per lane.
+#include <mutex>
+
 #include "common.h"
 
 namespace ldm {
@@ -688,6 +690,37 @@ int launch_mse(const float* a, const float* b, long n, float* partial_ws, float*
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, n, out);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
+}
+
+// The partial sums of the allocation-free entry point live in this array of the code object instead of a caller's
+// workspace.  Every GPU the library runs on holds its own copy at its own address; the name below is a host-side
+// stand-in, so host code only ever uses the per-device address that hipGetSymbolAddress returned.
+static __device__ __align__(256) float scratch[MSE_BLOCKS];
+static float* g_scratch_dev[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+static int mse_scratch(float** out) {
+    int dev = 0;
+    LDM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) LDM_FAIL(LDM_ERR_INVALID, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_dev[dev]) {
+        float* p = nullptr;
+        LDM_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) LDM_FAIL(LDM_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_dev[dev] = p;
+    }
+    *out = g_scratch_dev[dev];
+    return LDM_OK;
+}
+
+int launch_mse_noalloc(const float* a, const float* b, long n, float* out, hipStream_t s) {
+    LDM_REQUIRE(a && b && out && n > 0, "bad arguments");
+    LDM_REQUIRE(n <= LDM_MSE_NOALLOC_MAX_N, "more elements than the allocation-free entry point takes (LDM_MSE_NOALLOC_MAX_N)");
+    float* ws = nullptr;
+    LDM_TRY(mse_scratch(&ws));
+    // every one of the MSE_BLOCKS words is written by the first kernel before the second reads it: nothing to clear
+    return launch_mse(a, b, n, ws, out, s);
 }
 
 int launch_finite_check(const float* z, long n, int* flag, hipStream_t s) {

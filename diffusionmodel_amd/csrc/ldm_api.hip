@@ -1128,6 +1128,10 @@ int ldm_mse(const float* a, const float* b, long n, float* ws1024, float* out, v
     return launch_mse(a, b, n, ws1024, out, (hipStream_t)stream);
 }
 
+int ldm_mse_noalloc(const float* a, const float* b, long n, float* out, void* stream) {
+    return launch_mse_noalloc(a, b, n, out, (hipStream_t)stream);
+}
+
 int ldm_latent_is_finite(const float* z, long n, int* flag, void* stream) {
     return launch_finite_check(z, n, flag, (hipStream_t)stream);
 }

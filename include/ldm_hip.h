@@ -124,6 +124,13 @@ int ldm_add_noise(const float* x_dev, const float* noise_dev, const int* t_dev, 
 /* The loss value of DiffusionModel::forward, src/main.rs:665-671: out_dev[0] = mean((a - b)^2) over n f32
  * elements, summed in a fixed order.  ws1024_dev: 1024 floats of device scratch. */
 int ldm_mse(const float* a_dev, const float* b_dev, long n, float* ws1024_dev, float* out_dev, void* stream);
+/* ldm_mse for callers that cannot allocate device memory (code under hipGraph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  The 1024 partial sums live in a 4-KiB array
+ * inside the library's code object (one copy per GPU, held until the process ends) instead of a workspace argument;
+ * the call allocates nothing and returns the same value as ldm_mse, bit for bit.  n above LDM_MSE_NOALLOC_MAX_N is
+ * rejected.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race. */
+#define LDM_MSE_NOALLOC_MAX_N (1L << 36)
+int ldm_mse_noalloc(const float* a_dev, const float* b_dev, long n, float* out_dev, void* stream);
 
 /* ---- one convolution on NHWC tensors in the library's own layout (kernel-level operator) --- */
 /* The burn layers behind it: Conv2d 3x3 stride 1 / stride 2 padding 1 (src/main.rs:348-366,423-452,
