@@ -80,6 +80,13 @@
 #ifndef TAPCONV_SKINNY_MAXM
 #define TAPCONV_SKINNY_MAXM 512      // 1x1 convolutions over at most this many pixels take the skinny kernel
 #endif
+#ifndef TAPCONV_OUT_STORE
+#define TAPCONV_OUT_STORE 2      // 0 plain, 1 nontemporal, 2 sc1 (write-through, shipped), 3 sc0 sc1: see store_out
+#endif
+#ifndef TAPCONV_L3B_WN
+#define TAPCONV_L3B_WN 2         // waves over the 64 channels of the 16-row x 64-channel tile (256-channel level)
+#define TAPCONV_L3B_MINW 2
+#endif
 #ifndef TAPCONV_L3_WM
 #define TAPCONV_L3_WM 4
 #define TAPCONV_L3_WN 2
@@ -115,6 +122,7 @@ struct TapConvArgs {
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
 #ifdef TAPCONV_STAMP
     unsigned long long* dbg;     // diagnostic builds: cycle stamps of workgroup 0
+    unsigned long long* dbg_rt;  // diagnostic builds: {first, last} 100-MHz real-time stamp of every workgroup
 #endif
 };
 
@@ -165,6 +173,28 @@ __device__ __forceinline__ unsigned int f2u(float f) { return __builtin_bit_cast
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Output stores of the convolution kernels.  TAPCONV_OUT_STORE 2 = write-through (sc1): the bytes go to memory as the
+// kernel runs and the line is dropped from this XCD's L2, so a launch ends with nothing dirty to write back (a launch
+// that leaves B dirty bytes delays the next one by about B / 6 TB/s).  The instruction is written as asm so that the
+// cache bits are exactly these; like any store it counts once in vmcnt, in issue order, which the hand-counted waits
+// of the weight-stationary kernels rely on.  `s_nop 1` keeps the data registers intact until the store has read them.
+template <typename V>
+__device__ __forceinline__ void store_out(char* p, const V& v) {
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8, "8- or 16-byte stores");
+#if TAPCONV_OUT_STORE == 2
+    // (8-byte write-through stores are one fabric write each, 2.7 times the time per byte of a 16-byte one: those stay plain)
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *(V*)p = v;
+#elif TAPCONV_OUT_STORE == 3
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif TAPCONV_OUT_STORE == 1
+    __builtin_nontemporal_store(v, (V*)p);
+#else
+    *(V*)p = v;
+#endif
 }
 
 template <int N>
@@ -246,6 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     const unsigned wbuf0 = nhalo * HALO_BYTES;
     const unsigned dump = wbuf0 + RING * WSLAB;
 #ifdef TAPCONV_STAMP
+    if (a.dbg_rt && tid == 0) a.dbg_rt[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const unsigned stamp_base = dump + 1024 + (wave == 0 ? 0 : 2048);
     const bool stamp_on = a.dbg && blockIdx.x == 8 && (wave == 0 || wave == NWV - 1);
     unsigned long long tsA = 0, tsB = 0, tsC = 0;
@@ -592,8 +623,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         const bool st = ok[i] && (!(TAPCONV_ABLATE & 8) || v0[0] == 12345.678f);
         if (sizeof(T) == 4 || a.out_f32) {
             if (st) {
-                *(f32x4*)(a.out + eo[i] * 4) = v0;
-                *(f32x4*)(a.out + eo[i] * 4 + 16) = v1;
+                store_out(a.out + eo[i] * 4, v0);
+                store_out(a.out + eo[i] * 4 + 16, v1);
             }
         } else {
             u32x4 o;
@@ -601,7 +632,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
-            if (st) *(u32x4*)(a.out + eo[i] * 2) = o;
+            if (st) {
+                store_out(a.out + eo[i] * 2, o);
+            }
         }
     }
 #ifdef TAPCONV_STAMP
@@ -612,6 +645,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     if (stamp_on)
         for (int i = lane; i < 250; i += 64)
             a.dbg[(wave == 0 ? 0 : 256) + i] = *(const unsigned long long*)(smem + stamp_base + i * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's output stores have left
+    __syncthreads();
+    if (a.dbg_rt && tid == 0) a.dbg_rt[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -783,8 +819,8 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
                     z0[q] = ((z0[q] - v0[q] * k_s1m) * k_rsa) * k_c1 + v0[q] * k_c2;
                     z1[q] = ((z1[q] - v1[q] * k_s1m) * k_rsa) * k_c1 + v1[q] * k_c2;
                 }
-                *(f32x4*)(a.sched_z + eo) = z0;
-                *(f32x4*)(a.sched_z + eo + 4) = z1;
+                store_out((char*)(a.sched_z + eo), z0);
+                store_out((char*)(a.sched_z + eo + 4), z1);
                 v0 = z0;
                 v1 = z1;
             }
@@ -793,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
-            *(u32x4*)(a.out + eo * 2) = o;
+            store_out(a.out + eo * 2, o);
         }
     };
 
@@ -1057,7 +1093,7 @@ __global__ __launch_bounds__(512, 1) void upfuse_ws_kernel(const TapConvArgs a) 
         o[1] = pack2(v0[2], v0[3]);
         o[2] = pack2(v1[0], v1[1]);
         o[3] = pack2(v1[2], v1[3]);
-        *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
+        store_out(a.out + (eP + j * erow) * 2, o);
     };
 
     int buf = 0;
@@ -1237,13 +1273,13 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
-            *(u32x4*)(a.out + (eP + j * erow) * 2) = o;
+            store_out(a.out + (eP + j * erow) * 2, o);
         } else {
             const f32x4 v0 = accP[0][j] + b0;
             uint2 o;
             o.x = pack2(v0[0], v0[1]);
             o.y = pack2(v0[2], v0[3]);
-            *(uint2*)(a.out + (eP + j * erow) * 2) = o;
+            store_out(a.out + (eP + j * erow) * 2, o);
         }
     };
 
@@ -1405,7 +1441,7 @@ __global__ __launch_bounds__(256, 2) void ws1x1_kernel(const TapConvArgs a) {
         o[1] = pack2(v0[2], v0[3]);
         o[2] = pack2(v1[0], v1[1]);
         o[3] = pack2(v1[2], v1[3]);
-        *(u32x4*)(a.out + eo * 2) = o;
+        store_out(a.out + eo * 2, o);
     };
 
     int buf = 0;
@@ -1730,6 +1766,8 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     lds += 1024 + 4096;
     a.dbg = nullptr;
     if (const char* e = getenv("LDM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 16);
+    a.dbg_rt = nullptr;
+    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
     static_assert((size_t)TH * 16 * (BN * 4 + 16) <= 160 * 1024, "epilogue staging exceeds LDS");
     a.tiles_x = (a.Wg + 15) / 16;
@@ -1942,7 +1980,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if (bn == 128) {
             // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
             // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
-            if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L3>(a, nph, stream);
+            if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, TAPCONV_L3B_WN, 1, 3, 9, TAPCONV_L3B_MINW, TAPCONV_RING_L3>(a, nph, stream);
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);

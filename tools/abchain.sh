@@ -1,0 +1,7 @@
+#!/bin/bash
+shape=$1; shift
+for rep in 1 2; do
+for lib in "$@"; do
+    if [ "$lib" = default ]; then unset LDM_HIP_LIB; else export LDM_HIP_LIB=$PWD/devlibs/lib$lib.so; fi
+    timeout -k 10 100 python3 tools/chainbench.py $shape 2>&1 | grep "TF/s"
+done; done
