@@ -40,6 +40,7 @@
 #include <cstdlib>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 // Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
 // the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA.
@@ -79,6 +80,13 @@
 #endif
 #ifndef TAPCONV_SKINNY_MAXM
 #define TAPCONV_SKINNY_MAXM 512      // 1x1 convolutions over at most this many pixels take the skinny kernel
+#endif
+#ifndef TAPCONV_DDIM_Z_PLAIN
+#define TAPCONV_DDIM_Z_PLAIN 1
+#define TAPCONV_DDIM_O_PLAIN 0
+#endif
+#ifndef TAPCONV_STATIC_WAITS
+#define TAPCONV_STATIC_WAITS 1
 #endif
 #ifndef TAPCONV_OUT_STORE
 #define TAPCONV_OUT_STORE 2      // 0 plain, 1 nontemporal, 2 sc1 (write-through, shipped), 3 sc0 sc1: see store_out
@@ -196,6 +204,12 @@ __device__ __forceinline__ void store_out(char* p, const V& v) {
     *(V*)p = v;
 #endif
 }
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -458,6 +472,55 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     if constexpr (!(TAPCONV_ABLATE & 4)) load_frags(0, hbuf0, wbuf0, 0, wfA, xfA);
 
     int slot = 0, s = 0;   // slot = s % RING
+    // Every count a step waits for depends only on the tap and on whether the chunk is the last one.  With the tap
+    // loop unrolled over constant indices and the last chunk as a second copy of the body, each step's wait is one
+    // s_waitcnt with an immediate; computed at run time, the same counts were a tree of about ten scalar branches
+    // between the step's last MFMA and its barrier.
+    constexpr bool STATIC_WAITS = TAPCONV_STATIC_WAITS && !SKIPUP && !EARLY && NTAPS > D && TAPCONV_ALWAYS_ISSUE && !TAPCONV_ABLATE;
+    if constexpr (STATIC_WAITS) {
+        auto run_chunk = [&](int c, auto lastc_tag) {
+            constexpr bool LASTC = decltype(lastc_tag)::value;
+            const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES;
+            static_for<NTAPS>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int r = NTAPS - 1 - t;             // steps of this chunk after this one
+                STAMP_ISSUE(tsA);
+                if constexpr (t == 0 && !LASTC) issue_halo(c + 1);
+                // past the last slab the last one is issued again, into a ring slot that no later step reads
+                if constexpr (!LASTC || r >= D) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
+                else issue_w(nsteps - 1, slot == 0 ? RING - 1 : slot - 1);
+                const unsigned wb = wbuf0 + slot * WSLAB;
+                const int slot_next = slot + 1 == RING ? 0 : slot + 1;
+                constexpr bool wrap = t == NTAPS - 1;
+                const unsigned hbn = wrap ? hbuf0 + (LASTC ? 0 : ((c + 1) & 1)) * HALO_BYTES : hb;
+                load_frags(1, hb, wb, t, wfB, xfB);
+                mfma_batch(wfA, xfA);
+                interleave_reads_with_mfma();
+                // what may stay in flight across the barrier (see the run-time form below for the reasoning)
+                constexpr int need_k = LASTC ? (PUB < r ? PUB : r) : PUB;
+                constexpr int last_k = LASTC ? (D < r ? D : r) : D;
+                constexpr int nrep = LASTC && D > r ? D - r : 0;
+                constexpr int young = (LASTC && r == 0) ? 0 : (last_k - need_k) + nrep;
+                constexpr bool h_young = !LASTC && t <= D - 1 - PUB && t <= NTAPS - 1 - PUB;
+                STAMP_ISSUE(tsB);
+                wait_vmcnt<(young <= D - 1 ? young : 0) * NW + (h_young ? NHW : 0)>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TAPCONV_STAMP
+                STAMP_ISSUE(tsC);
+                STAMP_STORE(sidx, tsA); STAMP_STORE(sidx + 1, tsB); STAMP_STORE(sidx + 2, tsC);
+                sidx += 3;
+#endif
+                __builtin_amdgcn_s_barrier();
+                slot = slot_next;
+                load_frags(0, hbn, wbuf0 + slot * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
+                mfma_batch(wfB, xfB);
+                interleave_reads_with_mfma();
+                ++s;
+            });
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) run_chunk(c, std::bool_constant<false>{});
+        run_chunk(nchunks - 1, std::bool_constant<true>{});
+    } else {
     for (int c = 0; c < nchunks; ++c) {
         const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES;
         const bool more_chunks = c + 1 < nchunks;
@@ -528,6 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
                 interleave_reads_with_mfma();
             }
         }
+    }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -819,8 +883,13 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
                     z0[q] = ((z0[q] - v0[q] * k_s1m) * k_rsa) * k_c1 + v0[q] * k_c2;
                     z1[q] = ((z1[q] - v1[q] * k_s1m) * k_rsa) * k_c1 + v1[q] * k_c2;
                 }
+#if TAPCONV_DDIM_Z_PLAIN
+                *(f32x4*)(a.sched_z + eo) = z0;
+                *(f32x4*)(a.sched_z + eo + 4) = z1;
+#else
                 store_out((char*)(a.sched_z + eo), z0);
                 store_out((char*)(a.sched_z + eo + 4), z1);
+#endif
                 v0 = z0;
                 v1 = z1;
             }
@@ -829,7 +898,12 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
+#if TAPCONV_DDIM_O_PLAIN
+            if constexpr (DDIM) *(u32x4*)(a.out + eo * 2) = o;
+            else store_out(a.out + eo * 2, o);
+#else
             store_out(a.out + eo * 2, o);
+#endif
         }
     };
 
