@@ -303,14 +303,14 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 // overlap the other's MFMAs, measured no faster.)
 // ---------------------------------------------------------------------------------------------
 #ifndef ATTN_STREAM_XD
-#define ATTN_STREAM_XD 2
+#define ATTN_STREAM_XD 4
 #endif
 #ifndef ATTN_STREAM_SMALL
 #define ATTN_STREAM_SMALL 1
 #endif
 template <int D, int QF, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
-                                                                  int N, float scale_log2e) {
+                                                                  int N, float scale_log2e, int B) {
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
     // ring depth: four stages where they fit (C = 256), else two (C = 512: a stage is 64 KiB)
     constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4 * 2 * TILE <= 160 * 1024 ? 4 : 2;
@@ -323,8 +323,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * QB + wave * QF * 16;
+    // Blocks i and i + 8 share an XCD and its L2: all query blocks of one image get ids that are equal modulo 8, so
+    // the image's keys and values cross from memory into ONE L2 and the other query blocks read them there (in
+    // dispatch order the four query blocks of a 256-token image would sit on four XCDs and fetch K and V four times).
+    const int nqb = N / QB;
+    const int b = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7);
+    if (b >= B) return;                      // (the grid is padded to a multiple of eight images)
+    const int q0 = ((int)(blockIdx.x >> 3) % nqb) * QB + wave * QF * 16;
     const char* base = qkv + (size_t)b * N * 3 * RB;
     const int ntiles = N / KT;
 
@@ -543,8 +548,8 @@ static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStrea
     LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
-    dim3 grid((unsigned)(N / QB), (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);
+    dim3 grid((unsigned)((N / QB) * ((B + 7) / 8 * 8)));
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e, B);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }
