@@ -75,6 +75,9 @@
 #ifndef TAPCONV_S2WS_128
 #define TAPCONV_S2WS_128 1
 #endif
+#ifndef TAPCONV_S2WS_128_NF
+#define TAPCONV_S2WS_128_NF 2
+#endif
 #ifndef SKINNY3_MAXWG_F32
 #define SKINNY3_MAXWG_F32 1024       // f32 3x3 convolutions with at most this many skinny workgroups take the skinny kernel
 #endif
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
     constexpr int CIN_BYTES = NCH * 128, CB = 64 * NF;                           // output channels per workgroup
     static_assert(NG == 6, "six halo pieces per wave, chunk and tile");
     static_assert(NF == 1 || NF == 2, "one or two output-channel fragments per wave");
-    static_assert(KS * NF * 4 <= 144, "weights of a wave in registers");
+    static_assert(KS * NF * 4 <= 288, "weights of a wave in registers (288 at one wave per SIMD: the two-chunk, two-fragment form)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1918,16 +1921,17 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
         g_last_kernel = "void ldm::s2ws_kernel<1, 2>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
     } else {
+        constexpr int NF128 = TAPCONV_S2WS_128_NF;       // 16-channel fragments per wave: a workgroup owns 64 * NF128 output channels
         static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
-        LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<2, 1>, 160 * 1024, lds_set));
+        LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<2, NF128>, 160 * 1024, lds_set));
         const size_t lds = 2 * 2 * 6 * 4096;             // two windows of two chunks
-        const int ncb = a.cout / 64;                     // one workgroup per CU, the CUs split over the channel blocks
+        const int ncb = a.cout / (64 * NF128);           // one workgroup per CU, the CUs split over the channel blocks
         int per = ncu / ncb;
         if (per < 1) per = 1;
         if (per > a.ntiles) per = a.ntiles;
         a.nblk_n = per;
-        g_last_kernel = "void ldm::s2ws_kernel<2, 1>(ldm::TapConvArgs)";
-        hipLaunchKernelGGL((s2ws_kernel<2, 1>), dim3(per * ncb), dim3(256), lds, stream, a);
+        g_last_kernel = NF128 == 2 ? "void ldm::s2ws_kernel<2, 2>(ldm::TapConvArgs)" : "void ldm::s2ws_kernel<2, 1>(ldm::TapConvArgs)";
+        hipLaunchKernelGGL((s2ws_kernel<2, NF128>), dim3(per * ncb), dim3(256), lds, stream, a);
     }
     LDM_HIP(hipGetLastError());
     return LDM_OK;
