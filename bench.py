@@ -220,8 +220,12 @@ def main():
     # LDM_BENCH_BACKEND=gloo: developer rehearsal of the multi-rank control flow with all ranks on one GPU
     # (host-staged gather); the measured configuration is always nccl (= RCCL), one GPU per rank
     backend = "gloo" if fake else os.environ.get("LDM_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # LDM_BENCH_FORCE_PG=1: build the process group (and take the gather / reduce path) even with one rank, so that a
+    # one-GPU box can rehearse every RCCL call of the multi-GPU run
+    use_pg = world > 1 or os.environ.get("LDM_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -268,7 +272,7 @@ def main():
 
     def one_call():
         z = sample()
-        if world > 1:
+        if use_pg:
             pending.append(A.gather_latents_async(z, global_batch))
             while len(pending) > 2:           # bound the memory held by gathers in flight
                 pending.pop(0).wait()
@@ -281,7 +285,7 @@ def main():
         while pending:
             gathered = pending.pop(0).wait()
         sync()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             sync()
         return gathered
@@ -294,7 +298,7 @@ def main():
         out = one_call()
     gathered = fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         out = gathered
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -357,7 +361,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -160,29 +160,107 @@ def _insert(tree: dict, dotted: str, leaf: dict) -> None:
     tree[parts[-1]] = leaf
 
 
+# Fields of burn 0.18's layer modules that are not parameters: `#[derive(Module)]` records each as a constant, which
+# the named MessagePack recorder writes as nil, and `load_record` wants every field of the struct present as a key.
+_CONV_CONSTS = ("stride", "kernel_size", "dilation", "groups", "padding")
+_CONVT_CONSTS = ("stride", "kernel_size", "dilation", "groups", "padding", "padding_out", "channels")
+_BN_CONSTS = ("momentum", "epsilon")
+ENCODER_PREFIX = "vae.encoder."
+
+
+def record_inventory(in_channels: int = 3, latent_dimen: int = 64, time_embed_dim: int = 256, channels=(64, 128, 256),
+                     scaled_attention: bool = False) -> Dict[str, Optional[tuple]]:
+    """Every leaf of the DiffusionModel record by dotted field path: the shape of a tensor, or None for a constant
+    field (written as nil).  Struct fields from src/main.rs:22-33 (SimpleEncoder), 96-106 (SimpleDecoder), 172-175
+    (Vae), 238-243 (Attention), 279-282 (TimeAddition), 337-343 (ResidualBlock), 390-414 (Unet), 530-535
+    (DiffusionModel); the fields of Conv2d / ConvTranspose2d / BatchNorm / Linear from burn 0.18's layer structs."""
+    from .weights import LDMConfig, decoder_param_shapes, encoder_param_shapes, unet_param_shapes
+    inv: Dict[str, Optional[tuple]] = {}
+
+    def layer_consts(prefix: str, tensors: Dict[str, tuple], convT: set):
+        layers = {}
+        for name in tensors:
+            layer, leaf = name.rsplit(".", 1)
+            layers.setdefault(layer, set()).add(leaf)
+        for layer, leaves in layers.items():
+            if "gamma" in leaves:
+                consts = _BN_CONSTS
+            elif layer.split(".")[-1] in convT:
+                consts = _CONVT_CONSTS
+            elif len(tensors[layer + ".weight"]) == 4:
+                consts = _CONV_CONSTS
+            else:
+                consts = ()              # Linear: weight and bias only
+            for c in consts:
+                inv[prefix + layer + "." + c] = None
+
+    cfg = LDMConfig(latent_dimen, time_embed_dim, tuple(channels), scaled_attention)
+    unet = unet_param_shapes(cfg)
+    for k, shp in unet.items():
+        inv[UNET_PREFIX + k] = tuple(shp)
+    layer_consts(UNET_PREFIX, unet, {"up1", "up2"})
+    for c in ("pool1", "pool2", "mid_drop", "mid_atten.channels"):
+        inv[UNET_PREFIX + c] = None
+    if scaled_attention:
+        inv[UNET_PREFIX + "up_atten.channels"] = None
+    dec = decoder_param_shapes(in_channels, latent_dimen)
+    for k, shp in dec.items():
+        inv[DECODER_PREFIX + k] = tuple(shp)
+    layer_consts(DECODER_PREFIX, dec, {"reverse1", "reverse2", "reverse3"})
+    for c in ("drop1", "latent_dimen", "output"):
+        inv[DECODER_PREFIX + c] = None
+    enc = encoder_param_shapes(in_channels, latent_dimen)
+    for k, shp in enc.items():
+        inv[ENCODER_PREFIX + k] = tuple(shp)
+    layer_consts(ENCODER_PREFIX, enc, set())
+    for c in ("drop", "latent_dimen"):
+        inv[ENCODER_PREFIX + c] = None
+    inv["num_time"] = None
+    inv["latent_dimen"] = None
+    return inv
+
+
 def save_model_weights(path: str, unet: Dict[str, np.ndarray], decoder: Optional[Dict[str, np.ndarray]] = None,
-                       dtype: str = "F16", extra: Optional[Dict[str, np.ndarray]] = None) -> None:
-    """Write the container save_model writes (src/main.rs:839-847): half-precision elements by default, the UNet
-    below "unet", the decoder below "vae.decoder".  `extra` takes further full paths (e.g. "vae.encoder.conv1.weight")
-    for a caller who holds the encoder too; load_record on the Rust side needs every field of the struct present."""
+                       dtype: str = "F16", extra: Optional[Dict[str, np.ndarray]] = None,
+                       encoder: Optional[Dict[str, np.ndarray]] = None, in_channels: int = 3, latent_dimen: int = 64,
+                       time_embed_dim: int = 256, channels=(64, 128, 256), scaled_attention: bool = False,
+                       allow_partial: bool = False) -> None:
+    """Write the record save_model writes (src/main.rs:839-847): half-precision elements by default, every field of
+    every struct present: tensors as {"id", "param"}, constant fields (strides, paddings, Dropout, MaxPool2d, usize)
+    as nil, following `record_inventory`.  burn's load_record (:860-861) wants the whole DiffusionModel, so the
+    decoder and the VAE encoder's tensors (`encoder`, names as in weights.encoder_param_shapes) are required;
+    allow_partial=True writes whatever is given (a file this package's own reader takes, but NOT one the
+    reference's load_model can load).  `extra` takes further full paths.
+    PARITY UNPINNED: whether burn accepts the file could not be tried here (no cargo, no checkpoint of the reference)."""
     if dtype not in _DTYPES:
         raise ValueError(f"dtype {dtype!r}")
     to_np = lambda v: v.detach().cpu().numpy() if hasattr(v, "detach") else v
-    unet = {k: to_np(v) for k, v in unet.items()}
-    decoder = {k: to_np(v) for k, v in (decoder or {}).items()}
-    extra = {k: to_np(v) for k, v in (extra or {}).items()}
+    given: Dict[str, np.ndarray] = {}
+    for prefix, group in ((UNET_PREFIX, unet), (DECODER_PREFIX, decoder), (ENCODER_PREFIX, encoder), ("", extra)):
+        for k, v in (group or {}).items():
+            given[prefix + k] = np.asarray(to_np(v))
+    inv = record_inventory(in_channels, latent_dimen, time_embed_dim, channels, scaled_attention)
+    missing = [k for k, shp in inv.items() if shp is not None and k not in given]
+    if missing and not allow_partial:
+        raise ValueError(f"{len(missing)} tensors of the DiffusionModel record are missing (first {missing[0]!r}); the "
+                         "reference's load_model needs all of them (pass the decoder and the encoder, or allow_partial=True "
+                         "for a file only this package reads)")
+    for k, shp in inv.items():
+        if shp is not None and k in given and tuple(given[k].shape) != tuple(shp):
+            raise ValueError(f"{k} has shape {tuple(given[k].shape)}, the architecture needs {tuple(shp)}")
     item: dict = {}
-    for k, v in unet.items():
-        _insert(item, UNET_PREFIX + k, _encode_tensor(v, UNET_PREFIX + k, dtype))
-    for k, v in (decoder or {}).items():
-        _insert(item, DECODER_PREFIX + k, _encode_tensor(v, DECODER_PREFIX + k, dtype))
-    for k, v in (extra or {}).items():
+    for k, v in given.items():
         _insert(item, k, _encode_tensor(v, k, dtype))
-    item.setdefault("num_time", None)
-    item.setdefault("latent_dimen", None)
+    missing_set = set(missing)
+    for k, shp in inv.items():
+        if shp is None:
+            # a constant below a module none of whose tensors was given (allow_partial) would only create an empty shell
+            top = k.rsplit(".", 1)[0] + "." if "." in k else ""
+            if not allow_partial or not top or any(g.startswith(top) for g in given) or k in ("num_time", "latent_dimen"):
+                _insert(item, k, None)
     meta = {"float": {"F16": "f16", "BF16": "bf16", "F32": "f32", "F64": "f64"}[dtype], "int": "i16",
             "format": "burn_core::record::file::NamedMpkFileRecorder", "version": BURN_VERSION,
-            "settings": "diffusionmodel_amd"}
+            "settings": "HalfPrecisionSettings" if dtype == "F16" else "custom"}
     tmp = path + ".tmp"
     with open(tmp, "wb") as fh:
         fh.write(msgpack.packb({"metadata": meta, "item": item}, use_bin_type=True))

@@ -112,6 +112,19 @@ def decoder_param_shapes(output: int = 3, latent_dimen: int = 64) -> "OrderedDic
     return out
 
 
+def encoder_param_shapes(in_channels: int = 3, latent_dimen: int = 64) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Parameters of SimpleEncoder (src/main.rs:22-74) by Rust field path.  The encoder is not run by this
+    package; its shapes are needed to write a complete DiffusionModel record."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for name, bn, cin, cout in (("conv1", "bn_1", in_channels, 32), ("conv2", "bn_2", 32, 64), ("conv3", "bn_3", 64, 128)):
+        out[f"{name}.weight"] = (cout, cin, 3, 3); out[f"{name}.bias"] = (cout,)
+        for s in ("gamma", "beta", "running_mean", "running_var"):
+            out[f"{bn}.{s}"] = (cout,)
+    for name in ("mean", "variance"):
+        out[f"{name}.weight"] = (128 * 16 * 16, latent_dimen * 16); out[f"{name}.bias"] = (latent_dimen * 16,)
+    return out
+
+
 def synthetic_from_shapes(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     """Seeded f32 CPU tensors for the given name -> shape map (see the module docstring)."""
     g = torch.Generator().manual_seed(seed)

@@ -384,3 +384,25 @@ def test_finiteness_probe_and_fallbacks(A, O):
     n = torch.randn(2, 64, 4, 4, generator=torch.Generator().manual_seed(4)).cuda()
     assert m.forward(zbad, t, n, check_finite=True).item() == 100.0
     assert torch.equal(m.forward(z0, t, n, check_finite=True), m.forward(z0, t, n))
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py's multi-GPU path (nccl = RCCL process group, overlapped all_gather_into_tensor of the final latents,
+    barrier, MAX all-reduce of the time) rehearsed on one GPU with a one-rank group; the line it prints must
+    match the plain single-process run on the gathered batch size and be finite."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LDM_BENCH_FORCE_PG"] = "1"
+    _say("bench.py with a one-rank RCCL group")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "8", "--spatial", "16", "--steps", "3",
+                        "--warmup", "1", "--ddim-steps", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 1 and r["config"]["global_batch"] == 8 and r["value"] > 0

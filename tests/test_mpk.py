@@ -77,7 +77,7 @@ def test_save_then_load_round_trip(tmp_path, dtype, exact):
     w = A.make_synthetic_weights(cfg, 1)
     d = A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 2)
     f = str(tmp_path / "model.mpk")
-    A.save_model_weights(f, w, d, dtype=dtype)
+    A.save_model_weights(f, w, d, dtype=dtype, allow_partial=True)
     u2, d2 = A.load_model_weights(f, in_channels=3, latent_dimen=64, time_embed_dim=256)
     assert list(u2) == list(A.unet_param_shapes(cfg)) and list(d2) == list(A.decoder_param_shapes(3, 64))
     for src, got in ((w, u2), (d, d2)):
@@ -90,14 +90,14 @@ def test_save_then_load_round_trip(tmp_path, dtype, exact):
                 assert torch.equal(got[k], v.bfloat16().float())
     # a second save of what was loaded is byte-identical: the container is canonical for its contents
     g = str(tmp_path / "again.mpk")
-    A.save_model_weights(g, u2, d2, dtype=dtype)
+    A.save_model_weights(g, u2, d2, dtype=dtype, allow_partial=True)
     assert open(f, "rb").read() == open(g, "rb").read()
 
 
 def test_load_rejects_wrong_architecture_and_garbage(tmp_path):
     w = A.make_synthetic_weights(A.LDMConfig(), 1)
     f = str(tmp_path / "m.mpk")
-    A.save_model_weights(f, w)
+    A.save_model_weights(f, w, allow_partial=True)
     with pytest.raises(A.MpkFormatError, match="shape"):
         A.load_model_weights(f, channels=(128, 256, 512), scaled_attention=False)
     with pytest.raises(A.MpkFormatError, match="missing"):
@@ -124,11 +124,62 @@ def test_loaded_model_samples_like_the_model_it_was_saved_from(tmp_path):
     base = A.DiffusionModel(64, 3, 50, 256, dtype="bf16", weights=w, decoder_weights=d)
     ref = base.decode(base.ddim_sample(2, 5, spatial=4, z0=z0))
     f = str(tmp_path / "m.mpk")
-    A.save_model_weights(f, w, d, dtype="F32")
+    A.save_model_weights(f, w, d, dtype="F32", allow_partial=True)
     m = A.load_model(f, 3, 64, 50, 256)
     assert torch.equal(m.decode(m.ddim_sample(2, 5, spatial=4, z0=z0)), ref)
-    A.save_model_weights(f, w, d, dtype="F16")
+    A.save_model_weights(f, w, d, dtype="F16", allow_partial=True)
     m16 = A.load_model(f, 3, 64, 50, 256)
     half = lambda t: {k: v.half().float() for k, v in t.items()}
     b16 = A.DiffusionModel(64, 3, 50, 256, dtype="bf16", weights=half(w), decoder_weights=half(d))
     assert torch.equal(m16.decode(m16.ddim_sample(2, 5, spatial=4, z0=z0)), b16.decode(b16.ddim_sample(2, 5, spatial=4, z0=z0)))
+
+
+def test_full_record_has_every_field_of_every_struct(tmp_path):
+    """What burn's load_record needs (src/main.rs:860-861): every field of DiffusionModel, Unet, Vae, SimpleEncoder,
+    SimpleDecoder and of the burn layers below them present as a key: tensors as {"id", "param"} maps, constant
+    fields as nil.  The written tree is walked against the struct inventory (src/main.rs:22-33, 96-106, 172-175,
+    238-243, 279-282, 337-343, 390-414, 530-535)."""
+    import msgpack
+    from diffusionmodel_amd.weights import encoder_param_shapes
+    cfg = A.LDMConfig()
+    w = A.make_synthetic_weights(cfg, 1)
+    d = A.synthetic_from_shapes(A.decoder_param_shapes(3, 64), 2)
+    e = A.synthetic_from_shapes(encoder_param_shapes(3, 64), 3)
+    f = str(tmp_path / "full.mpk")
+    with pytest.raises(ValueError, match="missing"):
+        A.save_model_weights(f, w, d)                      # no encoder: not a record load_model could take
+    A.save_model_weights(f, w, d, encoder=e)
+    tree = msgpack.unpackb(open(f, "rb").read(), raw=False)
+    assert set(tree) == {"metadata", "item"} and tree["metadata"]["float"] == "f16"
+    item = tree["item"]
+    assert set(item) == {"unet", "vae", "num_time", "latent_dimen"} and item["num_time"] is None
+    assert set(item["vae"]) == {"encoder", "decoder"}
+    unet_fields = {"down1", "down_res1", "pool1", "down2", "down_res2", "pool2", "down3", "down_res3", "mid_res1", "mid_res2",
+                   "mid_atten", "mid_drop", "up1", "up_conv1", "up_res1", "up2", "up_conv2", "up_res2", "out_conv", "time_emb"}
+    assert set(item["unet"]) == unet_fields
+    assert item["unet"]["pool1"] is None and item["unet"]["mid_drop"] is None
+    assert set(item["unet"]["down1"]) == {"weight", "bias", "stride", "kernel_size", "dilation", "groups", "padding"}
+    assert set(item["unet"]["up1"]) == {"weight", "bias", "stride", "kernel_size", "dilation", "groups", "padding", "padding_out", "channels"}
+    assert set(item["unet"]["down_res1"]) == {"conv1", "conv2", "bn1", "bn2", "time"}
+    assert set(item["unet"]["down_res1"]["bn1"]) == {"gamma", "beta", "running_mean", "running_var", "momentum", "epsilon"}
+    assert set(item["unet"]["down_res1"]["time"]) == {"weight", "bias"}
+    assert set(item["unet"]["mid_atten"]) == {"question", "key", "val", "out", "channels"}
+    assert set(item["unet"]["time_emb"]) == {"linear1", "linear2"}
+    assert set(item["vae"]["encoder"]) == {"conv1", "bn_1", "conv2", "bn_2", "conv3", "bn_3", "mean", "variance", "drop", "latent_dimen"}
+    assert set(item["vae"]["decoder"]) == {"transfer", "drop1", "reverse1", "bn_1", "reverse2", "bn_2", "reverse3", "latent_dimen", "output"}
+    # every leaf is a tensor of the inventory's shape or nil, and nothing else is in the tree
+    inv = mpk.record_inventory(3, 64, 256)
+    seen = {}
+
+    def walk(node, path):
+        if node is None or mpk._is_tensor(node):
+            seen[path] = None if node is None else tuple(node["param"]["shape"])
+        else:
+            assert isinstance(node, dict), path
+            for k, v in node.items():
+                walk(v, f"{path}.{k}" if path else k)
+    walk(item, "")
+    assert seen == inv
+    # and this package reads its own full record back
+    u2, d2 = A.load_model_weights(f)
+    assert torch.equal(u2["down1.weight"], w["down1.weight"].half().float()) and d2 is not None
