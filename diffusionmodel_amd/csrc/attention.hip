@@ -303,7 +303,7 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 // overlap the other's MFMAs, measured no faster.)
 // ---------------------------------------------------------------------------------------------
 #ifndef ATTN_STREAM_XD
-#define ATTN_STREAM_XD 4
+#define ATTN_STREAM_XD 4         // depth of the fragment register ring at 16 queries per wave (at 32 the registers only allow 2)
 #endif
 #ifndef ATTN_STREAM_SMALL
 #define ATTN_STREAM_SMALL 1
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 
     // Fragment f = (ks, kf) of the K tile / df of the V tile goes through a register ring XD deep: the read
     // of fragment f + XD - 1 is issued before the wait for fragment f.
-    constexpr int XD = ATTN_STREAM_XD, NFK = KS * KF;
+    constexpr int XD = QF == 1 ? ATTN_STREAM_XD : 2, NFK = KS * KF;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto s_phase = [&](int t) {
         const unsigned kb = lds0 + (unsigned)(t & (NST - 1)) * 2 * TILE + klane;

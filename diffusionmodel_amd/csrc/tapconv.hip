@@ -88,9 +88,6 @@
 #define TAPCONV_DDIM_Z_PLAIN 1
 #define TAPCONV_DDIM_O_PLAIN 0
 #endif
-#ifndef TAPCONV_SPREAD_HALO
-#define TAPCONV_SPREAD_HALO 0    // 1: the next chunk's window is issued a piece or two per step (measured: no faster)
-#endif
 #ifndef TAPCONV_STATIC_WAITS
 #define TAPCONV_STATIC_WAITS 1
 #endif
@@ -347,8 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             hpix1[q] = ok ? ((2 * gy + py1) * a.Wout + 2 * gx + px1) : -1;
         }
     }
-    // pieces q0 .. q1-1 of this wave's NHW pieces of chunk c's window
-    auto issue_halo_range = [&](int c, int q0, int q1) {
+    auto issue_halo = [&](int c) {
         const bool src1 = c >= a.nch0;
         const char* base = (!src1 ? in0_img + c * 128 : in1_img + (c - a.nch0) * 128) + (lane & 1) * 16 +
                            (wave & 3) * 32;
@@ -356,7 +352,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         const unsigned hb = hbuf0 + (c & 1) * HALO_BYTES + (wave & 3) * HPLANE;
 #pragma unroll
         for (int q = 0; q < NHW; ++q) {
-            if (q < q0 || q >= q1) continue;
             const int grp = (wave + NWV * q) >> 2;       // wave-uniform
             int pix = hpix[q];
             if constexpr (SKIPUP) pix = src1 ? hpix1[q] : pix;
@@ -365,7 +360,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             if constexpr (!(TAPCONV_ABLATE & 16)) glds16(src, smem + dst);
         }
     };
-    auto issue_halo = [&](int c) { issue_halo_range(c, 0, NHW); };
     // Weight DMA: slab piece e = (plane e / (BN/32), 32 rows); wave w issues e = w + NWV*i.
     auto issue_w = [&](int s, int slot) {
         const char* sl = wbase + (size_t)s * wslab_stride + lane * 16;
@@ -494,12 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = NTAPS - 1 - t;             // steps of this chunk after this one
                 STAMP_ISSUE(tsA);
-                // The next chunk's window: all of it at the chunk's first tap, or (TAPCONV_SPREAD_HALO, measured no
-                // faster) a few pieces per step over the steps before the chunk's last one; within a step the window
-                // pieces come before the weight pieces.
-                constexpr int HPS = TAPCONV_SPREAD_HALO ? (NHW + NTAPS - 2) / (NTAPS - 1) : NHW;   // window pieces per step
-                constexpr int hq0 = t * HPS < NHW ? t * HPS : NHW, hq1 = (t + 1) * HPS < NHW ? (t + 1) * HPS : NHW;
-                if constexpr (!LASTC && hq1 > hq0) issue_halo_range(c + 1, hq0, hq1);
+                if constexpr (t == 0 && !LASTC) issue_halo(c + 1);
                 // past the last slab the last one is issued again, into a ring slot that no later step reads
                 if constexpr (!LASTC || r >= D) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
                 else issue_w(nsteps - 1, slot == 0 ? RING - 1 : slot - 1);
@@ -515,14 +504,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
                 constexpr int last_k = LASTC ? (D < r ? D : r) : D;
                 constexpr int nrep = LASTC && D > r ? D - r : 0;
                 constexpr int young = (LASTC && r == 0) ? 0 : (last_k - need_k) + nrep;
-                // window pieces that may stay in flight: those issued after slab s+PUB, i.e. in the steps after step
-                // s+PUB-D (within a step the window pieces precede the weight pieces); none at the chunk's last step,
-                // whose barrier opens the next chunk
-                constexpr int hfirst = t - (D - PUB) + 1 > 0 ? t - (D - PUB) + 1 : 0;
-                constexpr int hy0 = hfirst * HPS < NHW ? hfirst * HPS : NHW;
-                constexpr int h_young = (!LASTC && t <= NTAPS - 1 - PUB) ? hq1 - hy0 : 0;
+                constexpr bool h_young = !LASTC && t <= D - 1 - PUB && t <= NTAPS - 1 - PUB;
                 STAMP_ISSUE(tsB);
-                wait_vmcnt<(young <= D - 1 ? young : 0) * NW + h_young>();
+                wait_vmcnt<(young <= D - 1 ? young : 0) * NW + (h_young ? NHW : 0)>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef TAPCONV_STAMP
                 STAMP_ISSUE(tsC);
