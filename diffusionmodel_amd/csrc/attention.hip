@@ -308,9 +308,24 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 #ifndef ATTN_STREAM_SMALL
 #define ATTN_STREAM_SMALL 1
 #endif
-template <int D, int QF, int NW>
+#ifndef ATTN_FUSE_OUT
+#define ATTN_FUSE_OUT 1
+#endif
+// FUSE: the output projection of Attention and the residual add (src/main.rs:271-275) run in the same kernel.  The
+// normalised O of a wave's queries stays in registers as the B operand of a second product Y^T = Wo^T O^T, whose A
+// operand (rows = output channels) streams through the K half of the same ring stages as D/32 more tiles: the
+// arithmetic of the score phase with Wo^T in the place of K and O in the place of Q.  An accumulator register holds
+// O^T[d = 16 df + 4 g + r]; the B fragment of 32-channel block ks is made of accumulators 2 ks and 2 ks + 1, so its
+// element j of lane group g is channel 32 ks + (j < 4 ? 4 g + j : 16 + 4 g + j - 4): `wo` holds Wo^T [D][D] with the
+// input channels of every block of 32 in that order (pack_attention).  xres / out: [B, N, D]; bias f32 [D].
+struct AttnFuseArgs {
+    const char* wo;
+    const float* bias;
+    const char* xres;
+};
+template <int D, int QF, int NW, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
-                                                                  int N, float scale_log2e, int B) {
+                                                                  int N, float scale_log2e, int B, AttnFuseArgs fa) {
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
     // ring depth: four stages where they fit (C = 256), else two (C = 512: a stage is 64 KiB)
     constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4 * 2 * TILE <= 160 * 1024 ? 4 : 2;
@@ -332,6 +347,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     const int q0 = ((int)(blockIdx.x >> 3) % nqb) * QB + wave * QF * 16;
     const char* base = qkv + (size_t)b * N * 3 * RB;
     const int ntiles = N / KT;
+    constexpr int NWT = FUSE ? D / KT : 0;             // tiles of Wo^T behind the key/value tiles
+    const int ntot = ntiles + NWT;
+    static_assert(!FUSE || (QF == 1 && NST >= 3), "the fused projection is written for 16 queries per wave and the four-stage ring");
 
     // DMA pieces of this wave: piece i = wave + NW j covers the RPP rows from row i * RPP of the tile; piece j
     // lies j * NW * RPP rows below piece 0, which changes the row swizzle by an XOR on bits that piece 0's row
@@ -357,9 +375,31 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             at_glds16(sj + (vo ^ ((unsigned)((j * RPJ) & 7) << 5)), kd + TILE + j * NW * 1024);
         }
     };
+    // tile t >= ntiles: rows 32 (t - ntiles) .. of Wo^T into the K half of the stage (PPT pieces per wave, same swizzle)
+    unsigned woff = 0;
+    if constexpr (FUSE) {
+        const int o = wave * 1024 + lane * 16;
+        const int r = o / RB, sp = (o - r * RB) >> 4;
+        woff = r * RB + ((sp ^ (r & 15)) << 4);
+    }
+    auto issue_wtile = [&](int t) {
+        char* kd = smem + (t & (NST - 1)) * 2 * TILE + wave * 1024;
+        const char* src = fa.wo + (size_t)(t - ntiles) * KT * RB;
+        unsigned wo_ = woff;
+        asm volatile("" : "+v"(wo_));
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            at_glds16(src + (size_t)j * RPJ * RB + (wo_ ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
+    };
 #pragma unroll
     for (int t = 0; t < (NST >= 3 ? NST - 1 : 1); ++t)
         if (t < ntiles) issue_tile(t);
+        else if (FUSE) issue_wtile(t);
+    constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FUSE: the bias vector behind the ring (D floats)
+    if constexpr (FUSE) {
+        static_assert(D * 4 <= 1024, "the bias is one DMA piece");
+        if (wave == 0 && lane < D / 4) at_glds16((const char*)(fa.bias + lane * 4), smem + BIAS_OFF);
+    }
 
     u32x4 qreg[QF][KS];
 #pragma unroll
@@ -368,12 +408,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qreg[qf][ks] = *(const u32x4*)(row + (ks * 4 + g) * 16);
     }
+    // FUSE: the residual of this lane's outputs (query l15 of the wave, channels 32 j + 16 kf + 4 g .. + 3), loaded with Q
+    uint2 xr[FUSE ? NWT * 2 : 1];
+    if constexpr (FUSE) {
+        const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + g * 8;
+#pragma unroll
+        for (int i = 0; i < NWT * 2; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
+    }
     // a use of the loaded registers: the compiler waits for the loads here and not at the top of the
     // tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qreg[qf][ks]));
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int i = 0; i < NWT * 2; ++i) asm volatile("" : "+v"(xr[i]));
+    }
 
     f32x4 oacc[DF][QF];
 #pragma unroll
@@ -398,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     // of fragment f + XD - 1 is issued before the wait for fragment f.
     constexpr int XD = QF == 1 ? ATTN_STREAM_XD : 2, NFK = KS * KF;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto s_phase = [&](int t) {
+    auto s_phase = [&](int t, const u32x4 (&breg)[QF][KS]) {
         const unsigned kb = lds0 + (unsigned)(t & (NST - 1)) * 2 * TILE + klane;
 #pragma unroll
         for (int kf = 0; kf < KF; ++kf)
@@ -418,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf)
                 sacc[f & 1][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, kr[f % XD]), __builtin_bit_cast(bf16x8, qreg[qf][f >> 1]), sacc[f & 1][qf], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, kr[f % XD]), __builtin_bit_cast(bf16x8, breg[qf][f >> 1]), sacc[f & 1][qf], 0, 0, 0);
         });
     };
     // lane holds keys kf*16 + g*4 + r of query column l15; statistics in the log2 domain
@@ -490,6 +541,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         if (t + NST - 1 < ntiles) {
             issue_tile(t + NST - 1);
             at_wait_vmcnt<PPW>();
+        } else if (FUSE && t + NST - 1 < ntot) {
+            issue_wtile(t + NST - 1);
+            at_wait_vmcnt<PPT>();
         } else {
             at_wait_vmcnt<0>();
         }
@@ -501,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 
     if constexpr (NST >= 3) {
         for (int t = 0; t < ntiles; ++t) {
-            s_phase(t);
+            s_phase(t, qreg);
             softmax();
             pv_phase(t);
             tail(t);
@@ -511,7 +565,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         // whole interval to land
         for (int t = 0; t < ntiles; ++t) {
             if (t + 1 < ntiles) issue_tile(t + 1);
-            s_phase(t);
+            s_phase(t, qreg);
             softmax();
             pv_phase(t);
             at_wait_vmcnt<0>();
@@ -519,6 +573,41 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         }
     }
 
+    if constexpr (FUSE) {
+        // ---- normalise, round O to bf16 (as the unfused path stores it) and project: Y = O Wo + bias + x ----
+        float l = lrun[0];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        u32x4 obf[1][KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 lo = oacc[2 * ks][0] * inv, hi = oacc[2 * ks + 1][0] * inv;
+            obf[0][ks] = u32x4{at_pack2(lo[0], lo[1]), at_pack2(lo[2], lo[3]), at_pack2(hi[0], hi[1]), at_pack2(hi[2], hi[3])};
+        }
+        char* orow = out + ((size_t)b * N + q0 + l15) * RB;
+#pragma unroll
+        for (int j = 0; j < NWT; ++j) {
+            s_phase(ntiles + j, obf);                       // sacc[kf][0] = Y^T[32 j + 16 kf + 4 g + r][query l15]
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf) {
+                const int co = j * 32 + kf * 16 + g * 4;
+                const f32x4 bv = *(const f32x4*)(smem + BIAS_OFF + co * 4);
+                const uint2 r = xr[j * 2 + kf];
+                f32x4 v = sacc[kf][0] + bv;
+                v[0] += __builtin_bit_cast(float, r.x << 16);
+                v[1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
+                v[2] += __builtin_bit_cast(float, r.y << 16);
+                v[3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
+                uint2 w;
+                w.x = at_pack2(v[0], v[1]);
+                w.y = at_pack2(v[2], v[3]);
+                *(uint2*)(orow + co * 2) = w;
+            }
+            tail(ntiles + j);
+        }
+        return;
+    }
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
@@ -538,18 +627,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     }
 }
 
-template <int D, int QF, int NW>
-static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream) {
+template <int D, int QF, int NW, bool FUSE = false>
+static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream, AttnFuseArgs fa = AttnFuseArgs{}) {
     constexpr int QB = NW * QF * 16;
     constexpr size_t stage = (size_t)2 * 32 * D * 2;
-    constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage;
-    auto kern = attention_stream_kernel<D, QF, NW>;
+    constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage + (FUSE ? 1024 : 0);
+    auto kern = attention_stream_kernel<D, QF, NW, FUSE>;
     static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
     LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     dim3 grid((unsigned)((N / QB) * ((B + 7) / 8 * 8)));
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e, B);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e, B, fa);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }
@@ -568,6 +657,19 @@ static int launch_attn_cfg(const void* qkv, void* out, int B, int N, hipStream_t
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
+}
+
+// The shapes the fused form serves: bf16, 256 channels, token counts that take the 16-queries-per-wave instance.
+bool attention_can_fuse_out(int dtype, int B, int N, int C) {
+    return ATTN_FUSE_OUT && dtype == LDM_BF16 && C == 256 && ATTN_STREAM_SMALL && N % 64 == 0 && (long)B * ((N + 127) / 128) < 256 &&
+           !(N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256);
+}
+int launch_attention_fused(const void* qkv, const void* wo_packed, const float* bias, const void* xres, void* out, int B, int N,
+                           int C, hipStream_t stream) {
+    LDM_REQUIRE(qkv && wo_packed && bias && xres && out && B > 0 && N > 0, "bad arguments");
+    LDM_REQUIRE(B <= 65535 && attention_can_fuse_out(LDM_BF16, B, N, C), "shape not served by the fused attention kernel");
+    AttnFuseArgs fa{(const char*)wo_packed, bias, (const char*)xres};
+    return launch_attn_stream<256, 1, 4, true>(qkv, out, B, N, stream, fa);
 }
 
 int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C, hipStream_t stream) {

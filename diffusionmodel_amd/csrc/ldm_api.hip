@@ -225,6 +225,7 @@ struct ResBlockP {
 struct AttnP {
     PackedConv qkv, out;
     int C = 0;
+    void* wo_t = nullptr;   // out.weight transposed [C][C] bf16 in the order of launch_attention_fused (bf16, C = 256 only)
 };
 
 struct UnetBufs {   // NHWC activation buffers of one forward at fixed (B, H, W)
@@ -506,7 +507,19 @@ static int pack_attention(ldm_module* m, const std::string& prefix, int C, AttnP
     so.src = {C};
     so.w = [&](int, int, int co, int ci) { return (*wo)[(size_t)ci * C + co]; };
     so.bias = [&](int co) { return (*bo)[co]; };
-    return pack_conv(so, m->pool, &ap->out, nullptr);
+    LDM_TRY(pack_conv(so, m->pool, &ap->out, nullptr));
+    if (m->dtype == LDM_BF16 && C == 256) {
+        // row co, position 32 ks + 8 g + j  <-  input channel 32 ks + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+        std::vector<bf16_t> wt((size_t)C * C);
+        for (int co = 0; co < C; ++co)
+            for (int p = 0; p < C; ++p) {
+                const int ks = p >> 5, g = (p >> 3) & 3, j = p & 7;
+                const int ci = 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
+                wt[(size_t)co * C + p] = host_f2bf((*wo)[(size_t)ci * C + co]);
+            }
+        LDM_TRY(m->pool.upload(&ap->wo_t, wt.data(), wt.size() * 2));
+    }
+    return LDM_OK;
 }
 
 // One spatial layer between whole Hin x Win images as a matrix (see Dense4).  kind: CONV3x3_S1 / CONV3x3_S2 with
@@ -816,6 +829,8 @@ static int run_resblock(const ResBlockP& rp, const void* x, void* tmp, void* out
 static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, void* att, void* out, int B, int H, int W,
                          hipStream_t st) {
     LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (ap.wo_t && attention_can_fuse_out(dtype, B, H * W, ap.C))
+        return launch_attention_fused(qkv, ap.wo_t, ap.out.bias, x, out, B, H * W, ap.C, st);
     LDM_TRY(launch_attention(dtype, qkv, att, B, H * W, ap.C, st));
     LDM_TRY(run_conv(ap.out, att, ap.C, nullptr, 0, out, B, H, W, ACT_NONE, x, nullptr, 0, 0, st));
     return LDM_OK;
