@@ -43,7 +43,8 @@
 #include <utility>
 
 // Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
-// the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA.
+// the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA, 32 one weight fragment read per half step,
+// 64 every second window fragment read per half step (32 and 64 keep everything else, results are wrong: timing only).
 #ifndef TAPCONV_ABLATE
 #define TAPCONV_ABLATE 0
 #endif
@@ -392,10 +393,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         const char* hp = smem + hb + hlane;
         const int dx = tap_dx<NTAPS>(t);
         const int toff = (tap_dy<NTAPS>(t) * HW + (S == 2 ? (dx & 1) * HWE + (dx >> 1) : dx)) * 32;
+        // (ablation bits 32 / 64, timing only: one weight fragment read instead of NF / every second window fragment read)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const u32x4*)(wp + kk * 2 * WPLANE + nf * 512);
+        for (int nf = 0; nf < NF; ++nf)
+            wf[nf] = ((TAPCONV_ABLATE & 32) && nf > 0) ? wf[0] : *(const u32x4*)(wp + kk * 2 * WPLANE + nf * 512);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) xf[mf] = *(const u32x4*)(hp + kk * 2 * HPLANE + mf * (S * HW * 32) + toff);
+        for (int mf = 0; mf < MF; ++mf)
+            xf[mf] = ((TAPCONV_ABLATE & 64) && (mf & 1)) ? xf[mf - 1] : *(const u32x4*)(hp + kk * 2 * HPLANE + mf * (S * HW * 32) + toff);
     };
     auto mfma_batch = [&](const u32x4 (&wf)[NF], const u32x4 (&xf)[MF]) {
 #pragma unroll
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     // loop unrolled over constant indices and the last chunk as a second copy of the body, each step's wait is one
     // s_waitcnt with an immediate; computed at run time, the same counts were a tree of about ten scalar branches
     // between the step's last MFMA and its barrier.
-    constexpr bool STATIC_WAITS = TAPCONV_STATIC_WAITS && !SKIPUP && !EARLY && NTAPS > D && TAPCONV_ALWAYS_ISSUE && !TAPCONV_ABLATE;
+    constexpr bool STATIC_WAITS = TAPCONV_STATIC_WAITS && !SKIPUP && !EARLY && NTAPS > D && TAPCONV_ALWAYS_ISSUE && !(TAPCONV_ABLATE & 31);
     if constexpr (STATIC_WAITS) {
         auto run_chunk = [&](int c, auto lastc_tag) {
             constexpr bool LASTC = decltype(lastc_tag)::value;
