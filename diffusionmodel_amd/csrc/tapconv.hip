@@ -153,9 +153,15 @@ struct TapConvArgs {
             *(unsigned int*)(smem + stamp_base + (idx) * 8 + 4) = hi_;                                \
         }                                                                                            \
     } while (0)
+// The persistent kernels (diagnostic builds): 100-MHz real-time stamps of every workgroup, eight slots each: start, first
+// window and weights landed, end of each of the first four tiles, end (tools/wslife.py prints them).
+#define WS_STAMP(k_) do { if (a.dbg_rt && threadIdx.x == 0) a.dbg_rt[8 * blockIdx.x + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WS_STAMP_END() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WS_STAMP(6); } while (0)
 #else
 #define STAMP_ISSUE(var) do { } while (0)
 #define STAMP_STORE(idx, var) do { } while (0)
+#define WS_STAMP(k_) do { } while (0)
+#define WS_STAMP_END() do { } while (0)
 #endif
 
 
@@ -775,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
     int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
+    WS_STAMP(0);
 
     // this wave's 32 output channels of every (tap, half), straight from the packed weights (L2)
     u32x4 wreg[KS][NF];
@@ -1015,20 +1022,24 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     using W2 = std::integral_constant<int, 2>;
 
     tile_top(BoolC<true>{});
+    WS_STAMP(1);
     do_half(BoolC<false>{}, BoolC<false>{}, W0{});
     do_half(BoolC<true>{}, BoolC<true>{}, W2{});
+    WS_STAMP(2);
     tile += gridDim.x;
     buf ^= 1;
-    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+    for (int i = 1; tile < a.ntiles; tile += gridDim.x, buf ^= 1, ++i) {
         tile_top(BoolC<false>{});
         do_half(BoolC<false>{}, BoolC<true>{}, W0{});
         do_half(BoolC<true>{}, BoolC<true>{}, W1{});
+        if (i < 4) WS_STAMP(2 + i);
     }
     // the last half's epilogue
     wait_vmcnt<0>();
     read_staged();
 #pragma unroll
     for (int s = 0; s < KS; ++s) epi_slice(s);
+    WS_STAMP_END();
 
     if (DDIM && a.sched_ticket) {
         // Advance the sampler's step counter once per launch.  Every wave read the counter before its
@@ -1285,6 +1296,7 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int cb = blockIdx.x / a.nblk_n;
     int tile = blockIdx.x % a.nblk_n;          // the launcher never starts more workgroups per block than tiles
+    WS_STAMP(0);
 
     // slab (chunk c, tap t) = 4 pair planes of [cout][32 bytes]
     u32x4 wreg[KS][NF];
@@ -1428,17 +1440,21 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
     };
 
     tile_top(false);
+    WS_STAMP(1);
     do_tile(BoolC<false>{});
+    WS_STAMP(2);
     tile += a.nblk_n;
     buf ^= 1;
     bool stores_behind = false;
-    for (; tile < a.ntiles; tile += a.nblk_n, buf ^= 1) {
+    for (int i = 1; tile < a.ntiles; tile += a.nblk_n, buf ^= 1, ++i) {
         tile_top(stores_behind);
         do_tile(BoolC<true>{});
+        if (i < 4) WS_STAMP(2 + i);
         stores_behind = true;
     }
     epilogue_row(0);
     epilogue_row(1);
+    WS_STAMP_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1881,6 +1897,11 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
 
 template <int MODE>
 static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
+#ifdef TAPCONV_STAMP
+    a.dbg = nullptr;
+    a.dbg_rt = nullptr;
+    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
     int ncu = 0;
     LDM_TRY(device_cu_count(&ncu));
     a.tiles_x = a.Wg / 16;
@@ -1914,6 +1935,11 @@ static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
            a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
 }
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
+#ifdef TAPCONV_STAMP
+    a.dbg = nullptr;
+    a.dbg_rt = nullptr;
+    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
     int ncu = 0;
     LDM_TRY(device_cu_count(&ncu));
     a.tiles_x = a.Wout / 16;
