@@ -1,5 +1,5 @@
 #!/bin/bash
-# Benchmark lines and rocprofv3 summaries behind the numbers of DESIGN.md: run on the GPU box from the repository root,
+# Benchmark lines and rocprofv3 summaries of every benchmark configuration: run on the GPU box from the repository root,
 #   bash tools/final_profiles.sh gpurun_out/final TAG
 # then copy the files into profiles/ with the tag as prefix.
 set -e
