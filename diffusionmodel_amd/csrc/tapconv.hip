@@ -95,6 +95,12 @@
 #ifndef TAPCONV_OUT_STORE
 #define TAPCONV_OUT_STORE 2      // 0 plain, 1 nontemporal, 2 sc1 (write-through, shipped), 3 sc0 sc1: see store_out
 #endif
+#ifndef TAPCONV_S2WS_NBUF
+#define TAPCONV_S2WS_NBUF 2
+#endif
+#ifndef TAPCONV_S2WS_128_KSPL
+#define TAPCONV_S2WS_128_KSPL 1  // 128 -> 256 stride 2: the two input chunks on two groups of waves (two waves per SIMD)
+#endif
 #ifndef TAPCONV_L3B_WN
 #define TAPCONV_L3B_WN 2         // waves over the 64 channels of the 16-row x 64-channel tile (256-channel level)
 #define TAPCONV_L3B_MINW 2
@@ -132,6 +138,7 @@ struct TapConvArgs {
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
+    unsigned magic_tpi, magic_tx; // stride-2 persistent kernel: ceil(2^32 / tiles per image), ceil(2^32 / tiles_x) (see fast_div)
 #ifdef TAPCONV_STAMP
     unsigned long long* dbg;     // diagnostic builds: cycle stamps of workgroup 0
     unsigned long long* dbg_rt;  // diagnostic builds: {first, last} 100-MHz real-time stamp of every workgroup
@@ -220,6 +227,14 @@ template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// t / d for the tile arithmetic of a persistent kernel: d is a launch constant, magic = ceil(2^32 / d) comes from the
+// host, exact while t * d < 2^32 (the launcher checks it).  A run-time division is about 25 scalar instructions, in
+// front of every tile's barrier.
+__device__ __forceinline__ int fast_div(int t, int d, unsigned magic) {
+    return d == 1 ? t : (int)__umulhi((unsigned)t, magic);
+}
+static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -1276,21 +1291,36 @@ __global__ __launch_bounds__(512, 1) void upfuse_ws_kernel(const TapConvArgs a) 
 // epilogue, its stores and the next tile's DMA pieces are spread over the 72 MFMAs of the current tile.
 // Workgroup -> (block of 64*NF output channels, first tile); a.nblk_n = workgroups (= tile stride) per block.
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int NF>
-__global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapConvArgs a) {
+template <int NCH, int NF, int KSPL = 1>
+__global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(const TapConvArgs a) {
+    // KSPL = 2: eight waves; waves 4-7 take the second input chunk of every tile (NCH = 1 chunk per wave), so a wave
+    // holds 144 weight registers, two waves share a SIMD and the workgroup still owns 64 * NF output channels.  A wave
+    // finishes ONE output row of the tile: row kg of its own sums plus the partner wave's sums of that row, which cross
+    // LDS at the end of the tile (2 KiB per wave, double-buffered by tile parity).
+    static_assert(KSPL == 1 || (KSPL == 2 && NCH == 1 && NF == 2), "the chunk split is written for one chunk per wave, two fragments");
+    constexpr int NCT = NCH * KSPL;                                              // input chunks of the layer
     constexpr int TR = 2, HH = 2 * TR + 1, HW = 33, HWE = 17, HP = HH * HW;      // 165 window pixels
     constexpr int NG = (HP + 31) / 32;                                           // 6 groups of 32
-    constexpr int HPLANE = NG * 1024, CHUNK_BYTES = 4 * HPLANE, HALO_BYTES = NCH * CHUNK_BYTES;
+    // A pair plane holds exactly the 165 window pixels (32 bytes each): the last of the six 32-pixel DMA pieces starts at
+    // pixel 133 and overlaps the fifth (same bytes twice) instead of padding the plane to 192 slots.
+    constexpr int HPLANE = HP * 32, CHUNK_BYTES = 4 * HPLANE, HALO_BYTES = NCT * CHUNK_BYTES;
+    // Windows in LDS: that of tile i + NBUF - 1 is issued during tile i.  Three fit (with the compact planes, also next to
+    // the partial sums of the chunk split) and were measured: no faster per tile, and the two windows that every
+    // workgroup then requests at the start delay the first tile (13.3 against 12.8 us for 128 -> 256 channels).
+    constexpr int NBUF = TAPCONV_S2WS_NBUF;
+    static_assert(NBUF == 2 || NBUF == 3, "two or three windows");
+    static_assert(NBUF * HALO_BYTES + (KSPL == 2 ? 2 * 8 * 2048 : 0) <= 160 * 1024, "LDS budget");
     constexpr int KS = NCH * 18, XD = 4, NFR = NCH * HH * 6;                     // 30 fragments per chunk and tile
     constexpr int NPC = NCH * NG;                                                // DMA pieces per wave and tile
-    constexpr int CIN_BYTES = NCH * 128, CB = 64 * NF;                           // output channels per workgroup
+    constexpr int CIN_BYTES = NCT * 128, CB = 64 * NF;                           // output channels per workgroup
     static_assert(NG == 6, "six halo pieces per wave, chunk and tile");
     static_assert(NF == 1 || NF == 2, "one or two output-channel fragments per wave");
     static_assert(KS * NF * 4 <= 288, "weights of a wave in registers (288 at one wave per SIMD: the two-chunk, two-fragment form)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3, kg = wave_id >> 2;        // wave: channel quarter and window plane; kg: chunk group
     const int g = lane >> 4, l15 = lane & 15;
     const char* zero = (const char*)g_zero16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -1305,40 +1335,54 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-            wreg[ks][nf] = *(const u32x4*)(a.w + (size_t)(ks >> 1) * wslab + ((ks & 1) * 2 + (g >> 1)) * wplane +
+            wreg[ks][nf] = *(const u32x4*)(a.w + (size_t)(kg * NCH * 9 + (ks >> 1)) * wslab + ((ks & 1) * 2 + (g >> 1)) * wplane +
                                            (size_t)(cb * CB + (wave * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
 
-    // halo DMA: piece (chunk c, group q) of wave w = plane w of the chunk; slot -> window pixel, columns de-interleaved
-    int hyx[NG];
+    // Window DMA through a buffer resource over the tile's image.  Piece (chunk c, group q) of wave w = plane w of the
+    // chunk; a lane's byte offset inside the window does not depend on the tile (one register per group, columns
+    // de-interleaved: slot -> window pixel), the tile adds one scalar, the chunk an immediate.  With stride 2 and padding 1
+    // only the window's first row and first column can lie outside the image (tiles at the top / left border): those
+    // lanes get an offset beyond the resource, for which the hardware delivers zeros.  A tile past the end reads tile 0's
+    // window.
+    int hoff[NG];
+    unsigned hbits = 0;
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
-        const int hp = q * 32 + (lane >> 1);
+        const int hp = (q * 32 < HP - 32 ? q * 32 : HP - 32) + (lane >> 1);
         const int hy = hp / HW, hr = hp - hy * HW;
         const int hx = hr < HWE ? 2 * hr : 2 * (hr - HWE) + 1;
-        hyx[q] = hp < HP ? (hy << 8 | hx) : -1;
+        hoff[q] = (hy * a.Win + hx) * CIN_BYTES + (lane & 1) * 16 + wave * 32 + kg * NCH * 128;
+        hbits |= (unsigned)((hy == 0) | (hx == 0) << 1) << (2 * q);
     }
-    const char* hbase;
-    int hiy0, hix0;
-    bool hlive;
+    __amdgpu_buffer_rsrc_t hrsrc;
+    int horg;
+    unsigned hinval;
+    const int img_bytes = a.Hin * a.Win * CIN_BYTES;
     auto halo_origin = [&](int t) {
-        hlive = t < a.ntiles;
-        const int tt = hlive ? t : 0;
-        const int img = tt / tiles_per_img;
+        const int tt = t < a.ntiles ? t : 0;
+        const int img = fast_div(tt, tiles_per_img, a.magic_tpi);
         const int trem = tt - img * tiles_per_img;
-        hiy0 = (trem / a.tiles_x) * TR * 2 - 1;
-        hix0 = (trem % a.tiles_x) * 32 - 1;
-        hbase = a.in0 + (size_t)img * a.Hin * a.Win * CIN_BYTES + (lane & 1) * 16 + wave * 32;
+        const int ty = fast_div(trem, a.tiles_x, a.magic_tx), tx = trem - ty * a.tiles_x;
+        hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)img * img_bytes), 0, img_bytes, 0x00020000);
+        horg = ((ty * TR * 2 - 1) * a.Win + tx * 32 - 1) * CIN_BYTES;
+        hinval = hbits & ((unsigned)((ty == 0) | (tx == 0) << 1) * 0x555u);
     };
     auto halo_piece = [&](int p, int buf) {
-        const int c = p / NG, q = p - c * NG;
-        const int iy = hiy0 + (hyx[q] >> 8), ix = hix0 + (hyx[q] & 255);
-        const bool ok = hlive && hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-        const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * CIN_BYTES + c * 128 : zero;
-        glds16(src, smem + buf * HALO_BYTES + c * CHUNK_BYTES + wave * HPLANE + q * 1024);
+        const int c = p / NG, q = p % NG;                // c: chunk of this wave (compile time), on top of its group's first
+        const unsigned off = ((hinval >> (2 * q)) & 3u) ? 0xffffffffu : (unsigned)(horg + hoff[q] + c * 128);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            hrsrc, (__attribute__((address_space(3))) void*)(smem + buf * HALO_BYTES + (kg * NCH + c) * CHUNK_BYTES + wave * HPLANE +
+                                                             (q * 32 < HP - 32 ? q * 32 : HP - 32) * 32),
+            16, (int)off, 0, 0, 0);
     };
     halo_origin(tile);
 #pragma unroll
     for (int p = 0; p < NPC; ++p) halo_piece(p, 0);
+    if constexpr (NBUF == 3) {
+        halo_origin(tile + a.nblk_n);
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) halo_piece(p, 1);
+    }
 
     const unsigned hlane = (g >> 1) * HPLANE + l15 * 32 + (g & 1) * 16;
     // channels of a lane after the epilogue: NF = 2: 8 consecutive (two fragments exchanged between lane
@@ -1350,7 +1394,22 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
 
     f32x4 accP[NF][TR];
     size_t eP = 0;
-    auto epilogue_row = [&](int j) {
+    // chunk split: the other group's sums of this wave's row, left in LDS by the partner wave (wave_id ^ 4)
+    char* const xchg = smem + NBUF * HALO_BYTES;
+    int xpar = 0;                                     // parity of the tile whose sums are in accP
+    // (kg is uniform over the wave but not a constant: rows are picked by selects, not by indexing registers)
+    auto put_partial = [&](const f32x4 (&acc)[NF][TR], int par) {
+        char* dst = xchg + (par * 8 + wave_id) * 2048 + lane * 16;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) *(f32x4*)(dst + nf * 1024) = kg ? acc[nf][0] : acc[nf][TR - 1];
+    };
+    // own sums of row kg plus the partner's, into row 0 of accP (the row the epilogue then takes)
+    auto add_partial = [&]() {
+        const char* src = xchg + (xpar * 8 + (wave_id ^ 4)) * 2048 + lane * 16;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) accP[nf][0] = (kg ? accP[nf][TR - 1] : accP[nf][0]) + *(const f32x4*)(src + nf * 1024);
+    };
+    auto epilogue_row = [&](int j, int jout) {      // j: row of accP; jout: output row of the tile
         if constexpr (NF == 2) {
             f32x4 v0, v1;
 #pragma unroll
@@ -1366,28 +1425,34 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
-            store_out(a.out + (eP + j * erow) * 2, o);
+            store_out(a.out + (eP + jout * erow) * 2, o);
         } else {
             const f32x4 v0 = accP[0][j] + b0;
             uint2 o;
             o.x = pack2(v0[0], v0[1]);
             o.y = pack2(v0[2], v0[3]);
-            store_out(a.out + (eP + j * erow) * 2, o);
+            store_out(a.out + (eP + jout * erow) * 2, o);
         }
     };
 
     int buf = 0;
     size_t e0 = 0;
-    // per tile and wave: NPC DMA pieces, then the 2 stores of the previous tile's rows
-    // (the first tile has no previous rows to store: after it nothing is younger than its DMA pieces)
-    auto tile_top = [&](bool stores_behind) {
-        if (stores_behind) wait_vmcnt<2>();
-        else wait_vmcnt<0>();
+    // Per tile and wave, in issue order: the NPC DMA pieces of the window NBUF - 1 tiles ahead, then the NSTW stores of the
+    // previous tile's rows (none in the first tile).  Before tile i ITS window must have landed; younger than it are the
+    // pieces of the NBUF - 2 windows issued since and, from the third tile on, the stores of the tile before (with three
+    // windows, from the fourth tile on, also the stores of the tile before that: those are waited for as well, they were
+    // issued more than a tile ago).
+    constexpr int NSTW = KSPL == 2 ? 1 : 2;
+    auto tile_top = [&](int i) {
+        if (i >= 2) wait_vmcnt<(NBUF - 2) * NPC + NSTW>();
+        else wait_vmcnt<(NBUF - 2) * NPC>();
+        if constexpr (KSPL == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's partial sums are in LDS
         __builtin_amdgcn_s_barrier();
-        halo_origin(tile + a.nblk_n);
-        const int img = tile / tiles_per_img;
+        halo_origin(tile + (NBUF - 1) * a.nblk_n);
+        const int img = fast_div(tile, tiles_per_img, a.magic_tpi);
         const int trem = tile - img * tiles_per_img;
-        const int y0 = (trem / a.tiles_x) * TR, x0 = (trem % a.tiles_x) * 16;
+        const int ty = fast_div(trem, a.tiles_x, a.magic_tx);
+        const int y0 = ty * TR, x0 = (trem - ty * a.tiles_x) * 16;
         e0 = (((size_t)img * a.Hout + y0) * a.Wout + x0 + l15) * a.cout + co;
     };
     auto do_tile = [&](auto epi_tag) {
@@ -1397,7 +1462,7 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < TR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* hp0 = smem + buf * HALO_BYTES + hlane;
+        const char* hp0 = smem + buf * HALO_BYTES + kg * NCH * CHUNK_BYTES + hlane;
         // fragment f = (chunk c, window row h, column shift dx, channel half kk), kk fastest
         auto foff = [&](int f) {
             const int c = f / 30, fr = f % 30;
@@ -1410,10 +1475,14 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
             if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *(const u32x4*)(hp0 + foff(f + XD - 1));
-            if (f < NPC) halo_piece(f, buf ^ 1);
+            if (f < NPC) halo_piece(f, buf >= 1 ? buf - 1 : NBUF - 1);
             if (f == NPC) asm volatile("" ::: "memory");
-            if (EPI && f == NFR / 2 - 1) epilogue_row(0);
-            if (EPI && f == NFR - 4) epilogue_row(1);
+            if constexpr (KSPL == 2) {
+                if (EPI && f == NFR / 2 - 1) { add_partial(); epilogue_row(0, kg); }
+            } else {
+                if (EPI && f == NFR / 2 - 1) epilogue_row(0, 0);
+                if (EPI && f == NFR - 4) epilogue_row(1, 1);
+            }
             const int c = f / 30, fr = f % 30;
             const int h = fr / 6, dx = (fr % 6) >> 1, kk = fr & 1;
 #pragma unroll
@@ -1437,23 +1506,34 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void s2ws_kernel(const TapCo
 #pragma unroll
             for (int r = 0; r < TR; ++r) accP[nf][r] = acc[nf][r];
         eP = e0;
+        if constexpr (KSPL == 2) {
+            xpar ^= 1;
+            put_partial(acc, xpar);
+        }
     };
 
-    tile_top(false);
+    auto next_buf = [&]() { buf = buf + 1 == NBUF ? 0 : buf + 1; };
+    tile_top(0);
     WS_STAMP(1);
     do_tile(BoolC<false>{});
     WS_STAMP(2);
     tile += a.nblk_n;
-    buf ^= 1;
-    bool stores_behind = false;
-    for (int i = 1; tile < a.ntiles; tile += a.nblk_n, buf ^= 1, ++i) {
-        tile_top(stores_behind);
+    next_buf();
+    for (int i = 1; tile < a.ntiles; tile += a.nblk_n, ++i) {
+        tile_top(i);
         do_tile(BoolC<true>{});
         if (i < 4) WS_STAMP(2 + i);
-        stores_behind = true;
+        next_buf();
     }
-    epilogue_row(0);
-    epilogue_row(1);
+    if constexpr (KSPL == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        add_partial();
+        epilogue_row(0, kg);
+    } else {
+        epilogue_row(0, 0);
+        epilogue_row(1, 1);
+    }
     WS_STAMP_END();
 }
 
@@ -1932,7 +2012,10 @@ bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
 static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
     const bool c64 = a.nch0 == 1 && a.cout == 128, c128 = a.nch0 == 2 && a.cout == 256;
     return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || (c128 && TAPCONV_S2WS_128)) && a.nch1 == 0 &&
-           a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
+           a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 &&
+           // limits of fast_div and of the 32-bit offsets inside one image
+           (long)a.B * (a.Hout / 2) * (a.Wout / 16) * (a.Hout / 2) * (a.Wout / 16) < (1l << 32) && (long)a.Hin * a.Win * a.cin0_bytes < (1l << 31) &&
+           !TAPCONV_NO_WS64;
 }
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
@@ -1945,22 +2028,36 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     a.tiles_x = a.Wout / 16;
     a.tiles_y = a.Hout / 2;
     a.ntiles = a.tiles_x * a.tiles_y * a.B;
+    a.magic_tpi = div_magic(a.tiles_x * a.tiles_y);
+    a.magic_tx = div_magic(a.tiles_x);
     if (a.nch0 == 1) {
-        const size_t lds = 2 * 6 * 4096;                 // two windows of 5 x 33 pixels
+        const size_t lds = TAPCONV_S2WS_NBUF * 165 * 128;       // windows of 5 x 33 pixels
         a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-        g_last_kernel = "void ldm::s2ws_kernel<1, 2>(ldm::TapConvArgs)";
+        g_last_kernel = "void ldm::s2ws_kernel<1, 2, 1>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
+    } else if (TAPCONV_S2WS_128_KSPL) {
+        // two chunks split over two groups of four waves: one workgroup of eight waves per CU, 128 output channels each
+        static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
+        LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<1, 2, 2>, 160 * 1024, lds_set));
+        const size_t lds = TAPCONV_S2WS_NBUF * 2 * 165 * 128 + 2 * 8 * 2048;   // windows of two chunks + the partial sums of eight waves, twice
+        const int ncb = a.cout / 128;
+        int per = ncu / ncb;
+        if (per < 1) per = 1;
+        if (per > a.ntiles) per = a.ntiles;
+        a.nblk_n = per;
+        g_last_kernel = "void ldm::s2ws_kernel<1, 2, 2>(ldm::TapConvArgs)";
+        hipLaunchKernelGGL((s2ws_kernel<1, 2, 2>), dim3(per * ncb), dim3(512), lds, stream, a);
     } else {
         constexpr int NF128 = TAPCONV_S2WS_128_NF;       // 16-channel fragments per wave: a workgroup owns 64 * NF128 output channels
         static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
         LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<2, NF128>, 160 * 1024, lds_set));
-        const size_t lds = 2 * 2 * 6 * 4096;             // two windows of two chunks
+        const size_t lds = TAPCONV_S2WS_NBUF * 2 * 165 * 128;   // windows of two chunks
         const int ncb = a.cout / (64 * NF128);           // one workgroup per CU, the CUs split over the channel blocks
         int per = ncu / ncb;
         if (per < 1) per = 1;
         if (per > a.ntiles) per = a.ntiles;
         a.nblk_n = per;
-        g_last_kernel = NF128 == 2 ? "void ldm::s2ws_kernel<2, 2>(ldm::TapConvArgs)" : "void ldm::s2ws_kernel<2, 1>(ldm::TapConvArgs)";
+        g_last_kernel = NF128 == 2 ? "void ldm::s2ws_kernel<2, 2, 1>(ldm::TapConvArgs)" : "void ldm::s2ws_kernel<2, 1, 1>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<2, NF128>), dim3(per * ncb), dim3(256), lds, stream, a);
     }
     LDM_HIP(hipGetLastError());
