@@ -318,6 +318,14 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 // O^T[d = 16 df + 4 g + r]; the B fragment of 32-channel block ks is made of accumulators 2 ks and 2 ks + 1, so its
 // element j of lane group g is channel 32 ks + (j < 4 ? 4 g + j : 16 + 4 g + j - 4): `wo` holds Wo^T [D][D] with the
 // input channels of every block of 32 in that order (pack_attention).  xres / out: [B, N, D]; bias f32 [D].
+// Diagnostic builds (-DATTN_STAMP): 100-MHz real-time stamps of every workgroup of the streaming kernel, eight slots
+// each (start, first tiles landed, end of the key/value tiles, end), into the buffer whose address LDM_DBG_RT_PTR names.
+#ifdef ATTN_STAMP
+static __device__ unsigned long long* g_attn_rt = nullptr;
+#define AT_STAMP(k_) do { if (g_attn_rt && threadIdx.x == 0) g_attn_rt[8 * blockIdx.x + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_STAMP(k_) do { } while (0)
+#endif
 struct AttnFuseArgs {
     const char* wo;
     const float* bias;
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     const int nqb = N / QB;
     const int b = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7);
     if (b >= B) return;                      // (the grid is padded to a multiple of eight images)
+    AT_STAMP(0);
     const int q0 = ((int)(blockIdx.x >> 3) % nqb) * QB + wave * QF * 16;
     const char* base = qkv + (size_t)b * N * 3 * RB;
     const int ntiles = N / KT;
@@ -391,16 +400,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         for (int j = 0; j < PPT; ++j)
             at_glds16(src + (size_t)j * RPJ * RB + (wo_ ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
     };
-#pragma unroll
-    for (int t = 0; t < (NST >= 3 ? NST - 1 : 1); ++t)
-        if (t < ntiles) issue_tile(t);
-        else if (FUSE) issue_wtile(t);
     constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FUSE: the bias vector behind the ring (D floats)
     if constexpr (FUSE) {
         static_assert(D * 4 <= 1024, "the bias is one DMA piece");
         if (wave == 0 && lane < D / 4) at_glds16((const char*)(fa.bias + lane * 4), smem + BIAS_OFF);
     }
 
+    // Issue order of the prologue: the bias, Q and the residual first, then the first tiles.  vmcnt retires in issue
+    // order, so the wait in front of the first interval can leave the pieces of the second and third tile in flight.
     u32x4 qreg[QF][KS];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
@@ -415,6 +422,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 #pragma unroll
         for (int i = 0; i < NWT * 2; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
     }
+    asm volatile("" ::: "memory");
+    constexpr int NPRO = NST >= 3 ? NST - 1 : 1;       // tiles issued before the first interval
+#pragma unroll
+    for (int t = 0; t < NPRO; ++t)
+        if (t < ntiles) issue_tile(t);
+        else if (FUSE) issue_wtile(t);
+    asm volatile("" ::: "memory");
     // a use of the loaded registers: the compiler waits for the loads here and not at the top of the
     // tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
 #pragma unroll
@@ -535,14 +549,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
                     __builtin_bit_cast(bf16x8, vr[df % XD]), __builtin_bit_cast(bf16x8, pb[qf]), oacc[df][qf], 0, 0, 0);
         });
     };
-    // End of interval t: every wave is past barrier t-1, so stage (t-1) % 4 is free for tile t+3; then
-    // wait for this wave's pieces of tile t+2 (all but the ones just issued) and meet the other waves.
+    // End of interval t: every wave is past barrier t-1, so stage (t-1) % 4 is free for tile t+3.  The barrier that
+    // follows publishes tile t+1, the next one to be read: this wave waits for its pieces of THAT tile and leaves the
+    // pieces of tiles t+2 and t+3 in flight (a key/value tile is PPW pieces per wave, a tile of Wo^T PPT), so a tile has
+    // two intervals to land.  (Waiting for tile t+2 here as well made every interval one memory latency long: 1.3 us
+    // per 32 keys at 256 tokens, where an interval's arithmetic is a quarter of that.)
     auto tail = [&](int t) {
-        if (t + NST - 1 < ntiles) {
-            issue_tile(t + NST - 1);
+        const int t2 = t + NST - 2, t3 = t + NST - 1;            // the two youngest tiles that may exist
+        if (t3 < ntiles) {
+            issue_tile(t3);
+            at_wait_vmcnt<2 * PPW>();
+        } else if (FUSE && t3 < ntot) {
+            issue_wtile(t3);
+            if (t2 < ntiles) at_wait_vmcnt<PPW + PPT>();
+            else at_wait_vmcnt<2 * PPT>();
+        } else if (t2 < ntiles) {
             at_wait_vmcnt<PPW>();
-        } else if (FUSE && t + NST - 1 < ntot) {
-            issue_wtile(t + NST - 1);
+        } else if (FUSE && t2 < ntot) {
             at_wait_vmcnt<PPT>();
         } else {
             at_wait_vmcnt<0>();
@@ -550,8 +573,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         __builtin_amdgcn_s_barrier();
     };
 
-    at_wait_vmcnt<0>();
+    // the first tile (and everything older); the younger tiles of the prologue stay in flight where they are key/value
+    // tiles (with fewer key tiles than ring stages the prologue also holds tiles of Wo^T: then wait for all)
+    if (NST >= 3 && ntiles >= NPRO) at_wait_vmcnt<(NPRO - 1) * PPW>();
+    else at_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    AT_STAMP(1);
 
     if constexpr (NST >= 3) {
         for (int t = 0; t < ntiles; ++t) {
@@ -559,7 +586,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             softmax();
             pv_phase(t);
             tail(t);
+            if (t < 3) AT_STAMP(2 + t);
         }
+        AT_STAMP(5);
     } else {
         // two stages: tile t+1 goes into the stage that barrier t-1 freed, at the START of interval t, and has the
         // whole interval to land
@@ -606,6 +635,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             }
             tail(ntiles + j);
         }
+#ifdef ATTN_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AT_STAMP(6);
+#endif
         return;
     }
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
@@ -636,6 +669,12 @@ static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStrea
     static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
     LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
+#ifdef ATTN_STAMP
+    if (const char* e = getenv("LDM_DBG_RT_PTR")) {
+        unsigned long long* p = (unsigned long long*)strtoull(e, nullptr, 16);
+        LDM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_rt), &p, sizeof(p)));
+    }
+#endif
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     dim3 grid((unsigned)((N / QB) * ((B + 7) / 8 * 8)));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, (const char*)qkv, (char*)out, N, scale_log2e, B, fa);
