@@ -67,8 +67,11 @@
 #ifndef TAPCONV_RING_L2
 #define TAPCONV_RING_L2 3
 #endif
+#ifndef TAPCONV_RING_UP
+#define TAPCONV_RING_UP 3        // the fused up-sampling block at the 128-channel level (16 rows x 128 channels)
+#endif
 #ifndef TAPCONV_RING_L3
-#define TAPCONV_RING_L3 3
+#define TAPCONV_RING_L3 4
 #endif
 #ifndef TAPCONV_ALWAYS_ISSUE
 #define TAPCONV_ALWAYS_ISSUE 1
@@ -2199,7 +2202,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if constexpr (sizeof(T) == 2) {
             if (pc.ntaps1 != 1 || !cc.in1) LDM_FAIL(LDM_ERR_INVALID, "fused up-sampling conv needs its skip source");
             if (bn == 128) {
-                if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, 3, 1>(a, nph, stream);
+                if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, TAPCONV_RING_UP, 1>(a, nph, stream);
                 if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
                 return launch_cfg<T, 4, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
             }
