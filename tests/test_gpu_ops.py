@@ -248,7 +248,8 @@ def test_conv_ops_against_torch(A, kind, B, S, cin0, cin1, cout, act, res):
 
 
 # ---- stride-2 convolutions at the sizes of the weight-stationary kernels --------------------------
-@pytest.mark.parametrize("B,S,cin,cout", [(16, 64, 64, 128), (64, 32, 128, 256), (70, 32, 128, 256), (3, 32, 128, 256)])
+# (16, 64, 128, 256): two tiles per output row, so the 128 -> 256 kernel sees tiles on and off the left border
+@pytest.mark.parametrize("B,S,cin,cout", [(16, 64, 64, 128), (64, 32, 128, 256), (70, 32, 128, 256), (3, 32, 128, 256), (16, 64, 128, 256)])
 def test_conv_stride2_large(A, B, S, cin, cout):
     """conv3x3 / stride 2 (down2, down3; src/main.rs:434-452) through the kernel-level operator at batch
     sizes that reach the weight-stationary kernels (and one that does not), against torch on the same
