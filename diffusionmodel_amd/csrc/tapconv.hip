@@ -104,6 +104,9 @@
 #ifndef TAPCONV_S2WS_128_KSPL
 #define TAPCONV_S2WS_128_KSPL 1  // 128 -> 256 stride 2: the two input chunks on two groups of waves (two waves per SIMD)
 #endif
+#ifndef TAPCONV_WS64_EARLY
+#define TAPCONV_WS64_EARLY 5
+#endif
 #ifndef TAPCONV_L3B_WN
 #define TAPCONV_L3B_WN 2         // waves over the 64 channels of the 16-row x 64-channel tile (256-channel level)
 #define TAPCONV_L3B_MINW 2
@@ -141,6 +144,7 @@ struct TapConvArgs {
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
+    int early_num;               // 64-channel persistent kernel: eighths of a pair's tiles for its first workgroup (0: even split)
     unsigned magic_tpi, magic_tx; // stride-2 persistent kernel: ceil(2^32 / tiles per image), ceil(2^32 / tiles_x) (see fast_div)
 #ifdef TAPCONV_STAMP
     unsigned long long* dbg;     // diagnostic builds: cycle stamps of workgroup 0
@@ -798,7 +802,28 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     const char* zero = (const char*)g_zero16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
-    int tile = blockIdx.x;          // the launcher never starts more workgroups than tiles
+    // Tiles of this workgroup: tile0, tile0 + tstride, ... (nmine of them; the launcher never starts more workgroups than
+    // tiles).  Even split: workgroup b takes every gridDim.x-th tile from b.  Uneven split (a.early_num > 0, grid = two
+    // workgroups per CU): the workgroups b and b + grid/2 share the tiles p, p + grid/2, p + grid, ... of their pair p;
+    // b < grid/2 takes the first early_num/8 of them.  Measured: the dispatcher fills every CU once before it places a
+    // second workgroup, the second one's weights and first window land 1.9 us after the first one's, and the SIMD's
+    // arbiter serves the older wave first (2.9 against 4.4 us per tile while both run): with equal shares the launch
+    // ends with the second workgroups, 4.5 us after the first ones are done.
+    int tile, tstride, nmine;
+    if (a.early_num > 0) {
+        const int half = (int)gridDim.x >> 1, pr = (int)blockIdx.x >= half ? (int)blockIdx.x - half : (int)blockIdx.x;
+        const int npair = (a.ntiles - pr + half - 1) / half;
+        int ne = (npair * a.early_num + 4) >> 3;
+        if (ne > npair - 1) ne = npair - 1;          // the second workgroup keeps at least one tile
+        tstride = half;
+        tile = (int)blockIdx.x >= half ? pr + ne * half : pr;
+        nmine = (int)blockIdx.x >= half ? npair - ne : ne;
+    } else {
+        tile = blockIdx.x;
+        tstride = gridDim.x;
+        nmine = (a.ntiles - tile + tstride - 1) / tstride;
+    }
+    int kt = 0;                     // index of the current tile in this workgroup's list
     WS_STAMP(0);
 
     // this wave's 32 output channels of every (tap, half), straight from the packed weights (L2)
@@ -954,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         else wait_vmcnt<2 * NST>();
         // every wave is done reading the other halo buffer, which the next tile's pieces overwrite
         __builtin_amdgcn_s_barrier();
-        halo_origin(tile + (int)gridDim.x);
+        halo_origin(kt + 1 < nmine ? tile + tstride : a.ntiles);
         img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
@@ -1044,13 +1069,13 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     do_half(BoolC<false>{}, BoolC<false>{}, W0{});
     do_half(BoolC<true>{}, BoolC<true>{}, W2{});
     WS_STAMP(2);
-    tile += gridDim.x;
+    tile += tstride;
     buf ^= 1;
-    for (int i = 1; tile < a.ntiles; tile += gridDim.x, buf ^= 1, ++i) {
+    for (kt = 1; kt < nmine; ++kt, tile += tstride, buf ^= 1) {
         tile_top(BoolC<false>{});
         do_half(BoolC<false>{}, BoolC<true>{}, W0{});
         do_half(BoolC<true>{}, BoolC<true>{}, W1{});
-        if (i < 4) WS_STAMP(2 + i);
+        if (kt < 4) WS_STAMP(2 + kt);
     }
     // the last half's epilogue
     wait_vmcnt<0>();
@@ -1978,6 +2003,15 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
     return 4;
 }
 
+// share of a pair's tiles that the first-placed workgroup takes, in eighths (0 = even split), per epilogue mode;
+// LDM_WS64_EARLY overrides it for measurements
+static int ws64_early_eighths(int mode) {
+    static const int env = [] { const char* e = getenv("LDM_WS64_EARLY"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env >= 8 ? 7 : env;
+    (void)mode;
+    return TAPCONV_WS64_EARLY;
+}
+
 template <int MODE>
 static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
@@ -1993,6 +2027,8 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
     a.nblk_n = 1;
     const size_t lds = 2 * 6 * 4096 + 4 * 4 * 1024;  // two halo buffers of 10x18 pixels + staged epilogue inputs
     const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+    // uneven shares for the two workgroups of a CU once every pair has at least four tiles (see the kernel)
+    a.early_num = (grid == 2 * ncu && a.ntiles >= 4 * ncu) ? ws64_early_eighths(MODE) : 0;
     static const std::string name = "void ldm::tapconv_ws64_kernel<" + std::to_string(MODE) + ">(ldm::TapConvArgs)";
     g_last_kernel = name.c_str();
     hipLaunchKernelGGL(tapconv_ws64_kernel<MODE>, dim3(grid), dim3(256), lds, stream, a);
