@@ -104,6 +104,9 @@
 #ifndef TAPCONV_S2WS_128_KSPL
 #define TAPCONV_S2WS_128_KSPL 1  // 128 -> 256 stride 2: the two input chunks on two groups of waves (two waves per SIMD)
 #endif
+#ifndef TAPCONV_S2WS_EARLY
+#define TAPCONV_S2WS_EARLY 5
+#endif
 #ifndef TAPCONV_WS64_EARLY
 #define TAPCONV_WS64_EARLY 5
 #endif
@@ -144,7 +147,7 @@ struct TapConvArgs {
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
-    int early_num;               // 64-channel persistent kernel: eighths of a pair's tiles for its first workgroup (0: even split)
+    int early_num;               // persistent kernels with two workgroups per CU: eighths of a pair's tiles for its first workgroup (0: even split)
     unsigned magic_tpi, magic_tx; // stride-2 persistent kernel: ceil(2^32 / tiles per image), ceil(2^32 / tiles_x) (see fast_div)
 #ifdef TAPCONV_STAMP
     unsigned long long* dbg;     // diagnostic builds: cycle stamps of workgroup 0
@@ -1353,7 +1356,24 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
     const char* zero = (const char*)g_zero16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int cb = blockIdx.x / a.nblk_n;
-    int tile = blockIdx.x % a.nblk_n;          // the launcher never starts more workgroups per block than tiles
+    // Tiles of this workgroup: tile, tile + tstride, ... (nmine of them; the launcher never starts more workgroups per
+    // block than tiles).  a.early_num > 0 (one channel block, two workgroups per CU): uneven shares for the workgroups b
+    // and b + grid/2, as in tapconv_ws64_kernel.
+    int tile, tstride, nmine;
+    if (a.early_num > 0) {
+        const int half = a.nblk_n >> 1, bb = (int)blockIdx.x, pr = bb >= half ? bb - half : bb;
+        const int npair = (a.ntiles - pr + half - 1) / half;
+        int ne = (npair * a.early_num + 4) >> 3;
+        if (ne > npair - 1) ne = npair - 1;
+        tstride = half;
+        tile = bb >= half ? pr + ne * half : pr;
+        nmine = bb >= half ? npair - ne : ne;
+    } else {
+        tile = blockIdx.x % a.nblk_n;
+        tstride = a.nblk_n;
+        nmine = (a.ntiles - tile + tstride - 1) / tstride;
+    }
+    int kt = 0;
     WS_STAMP(0);
 
     // slab (chunk c, tap t) = 4 pair planes of [cout][32 bytes]
@@ -1407,7 +1427,7 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
 #pragma unroll
     for (int p = 0; p < NPC; ++p) halo_piece(p, 0);
     if constexpr (NBUF == 3) {
-        halo_origin(tile + a.nblk_n);
+        halo_origin(1 < nmine ? tile + tstride : a.ntiles);
 #pragma unroll
         for (int p = 0; p < NPC; ++p) halo_piece(p, 1);
     }
@@ -1476,7 +1496,7 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
         else wait_vmcnt<(NBUF - 2) * NPC>();
         if constexpr (KSPL == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's partial sums are in LDS
         __builtin_amdgcn_s_barrier();
-        halo_origin(tile + (NBUF - 1) * a.nblk_n);
+        halo_origin(kt + NBUF - 1 < nmine ? tile + (NBUF - 1) * tstride : a.ntiles);
         const int img = fast_div(tile, tiles_per_img, a.magic_tpi);
         const int trem = tile - img * tiles_per_img;
         const int ty = fast_div(trem, a.tiles_x, a.magic_tx);
@@ -1545,12 +1565,12 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
     WS_STAMP(1);
     do_tile(BoolC<false>{});
     WS_STAMP(2);
-    tile += a.nblk_n;
+    tile += tstride;
     next_buf();
-    for (int i = 1; tile < a.ntiles; tile += a.nblk_n, ++i) {
-        tile_top(i);
+    for (kt = 1; kt < nmine; ++kt, tile += tstride) {
+        tile_top(kt);
         do_tile(BoolC<true>{});
-        if (i < 4) WS_STAMP(2 + i);
+        if (kt < 4) WS_STAMP(2 + kt);
         next_buf();
     }
     if constexpr (KSPL == 2) {
@@ -2056,6 +2076,10 @@ static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
            (long)a.B * (a.Hout / 2) * (a.Wout / 16) * (a.Hout / 2) * (a.Wout / 16) < (1l << 32) && (long)a.Hin * a.Win * a.cin0_bytes < (1l << 31) &&
            !TAPCONV_NO_WS64;
 }
+static int s2ws_early_eighths() {
+    static const int env = [] { const char* e = getenv("LDM_S2WS_EARLY"); return e ? atoi(e) : -1; }();
+    return env >= 0 ? (env >= 8 ? 7 : env) : TAPCONV_S2WS_EARLY;
+}
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
     a.dbg = nullptr;
@@ -2072,6 +2096,7 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     if (a.nch0 == 1) {
         const size_t lds = TAPCONV_S2WS_NBUF * 165 * 128;       // windows of 5 x 33 pixels
         a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
+        a.early_num = (a.nblk_n == 2 * ncu && a.ntiles >= 4 * ncu) ? s2ws_early_eighths() : 0;
         g_last_kernel = "void ldm::s2ws_kernel<1, 2, 1>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
     } else if (TAPCONV_S2WS_128_KSPL) {
