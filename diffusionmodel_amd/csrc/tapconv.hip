@@ -67,6 +67,13 @@
 #ifndef TAPCONV_RING_L2
 #define TAPCONV_RING_L2 3
 #endif
+#ifndef TAPCONV_L2_WM
+#define TAPCONV_L2_WM 8          // waves over the rows / channels of the 16-row x 128-channel tile (128-channel level, bf16)
+#define TAPCONV_L2_WN 2
+#endif
+#ifndef TAPCONV_UP_WM
+#define TAPCONV_UP_WM 8          // the same for the fused up-sampling block (x 2 waves over the channels)
+#endif
 #ifndef TAPCONV_RING_UP
 #define TAPCONV_RING_UP 3        // the fused up-sampling block at the 128-channel level (16 rows x 128 channels)
 #endif
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     constexpr bool SKIPUP = NT1 != NTAPS;
     static_assert(!SKIPUP || (NTAPS == 4 && NT1 == 1 && S == 1), "single-tap second source: transposed conv only");
     constexpr int NWV = WM * WN;
-    static_assert(NWV == 4 || NWV == 8, "four or eight waves");
+    static_assert(NWV == 4 || NWV == 8 || NWV == 16, "four, eight or sixteen waves");
     constexpr int TW = 16;
     constexpr int HH = (TH - 1) * S + KEXT;
     constexpr int HW = (TW - 1) * S + KEXT;
@@ -2223,6 +2230,9 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
     const long tx = (a.Wg + 15) / 16;
     const long t16 = tx * ((a.Hg + 15) / 16) * a.B, t8 = tx * ((a.Hg + 7) / 8) * a.B;
     const int nph = pc.nphase;
+    int ncu_dev = 0;
+    LDM_TRY(device_cu_count(&ncu_dev));
+    const bool one_round = t16 * nblk_n * nph <= ncu_dev;      // 16-row tiles: at most one workgroup per CU
     if (pc.kind == CONV3x3_S2) {
         // one input chunk: a two-deep weight ring leaves room for two workgroups per CU, which hides the
         // halo prologue of one behind the MFMAs of the other (32 -> 24 us at 64 -> 128 channels)
@@ -2250,6 +2260,10 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
             // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
             // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
             if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, TAPCONV_L3B_WN, 1, 3, 9, TAPCONV_L3B_MINW, TAPCONV_RING_L3>(a, nph, stream);
+            // a launch of a single round of workgroups runs the tile with sixteen waves (four per SIMD cover each other's
+            // barrier and DMA stalls: 24.1 -> 23.1 us at 256 workgroups); over many rounds eight waves are 1 % faster
+            if (th == 16 && sizeof(T) == 2 && one_round)
+                return launch_cfg<T, 16, 128, TAPCONV_L2_WM, TAPCONV_L2_WN, 1, 3, 9, TAPCONV_L2_WM * TAPCONV_L2_WN / 4, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
             if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
@@ -2263,6 +2277,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if constexpr (sizeof(T) == 2) {
             if (pc.ntaps1 != 1 || !cc.in1) LDM_FAIL(LDM_ERR_INVALID, "fused up-sampling conv needs its skip source");
             if (bn == 128) {
+                if (th == 16 && one_round) return launch_cfg<T, 16, 128, TAPCONV_UP_WM, 2, 1, 3, 4, TAPCONV_UP_WM / 2, TAPCONV_RING_UP, 1>(a, nph, stream);   // 28.9 -> 26.3 us
                 if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, TAPCONV_RING_UP, 1>(a, nph, stream);
                 if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
                 return launch_cfg<T, 4, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
