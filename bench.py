@@ -100,12 +100,12 @@ def time_sched_kernel(B, S, C, iters=30):
     eps read, noise read = 16 bytes per element.  (average ms, algorithmic bytes per launch)."""
     import torch
     import diffusionmodel_amd as A
-    from oracle import ldm_oracle as O       # coefficient row only (host table); nothing of it is timed
+    from diffusionmodel_amd import schedule
     gen = torch.Generator(device="cuda").manual_seed(2)
     z = torch.randn(B, C, S, S, device="cuda", generator=gen)
     eps = torch.randn(B, C, S, S, device="cuda", generator=gen)
     noise = torch.randn(B, C, S, S, device="cuda", generator=gen)
-    row = O.ddpm_coefficients(1000)[500]
+    row = schedule.ddpm_coefficients(1000)[500]
     ms = _event_time(lambda: A.sched_step(z, eps, row, "ddpm", last=False, noise=noise), iters)
     return ms, 16.0 * z.numel()
 
@@ -164,9 +164,14 @@ def _free_port():
     return p
 
 
-def launch_ranks(n):
-    """Starts n fresh copies of this script, one per rank, and waits for them.  This process has not initialised the
-    GPU (torch is not even imported yet), and it never replaces itself: children are ordinary subprocesses."""
+def launch_ranks(n, deadline_s=None):
+    """Starts n fresh copies of this script, one per rank, and supervises them.  This process has not initialised the
+    GPU (torch is not even imported yet), and it never replaces itself: children are ordinary subprocesses.
+    The first rank that exits with an error ends the run: the others (which would wait for it in a collective for
+    ever, holding their GPUs) are terminated, then killed, and its status is returned.  The same happens when the
+    whole run exceeds `deadline_s` seconds (LDM_BENCH_DEADLINE_S, default 3000): status 124."""
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("LDM_BENCH_DEADLINE_S", "3000"))
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
@@ -174,11 +179,33 @@ def launch_ranks(n):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    t_end = time.monotonic() + deadline_s
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    return rc
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1]
+            print(f"bench: rank {bad[0][0]} exited with status {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > t_end:
+            rc = 124
+            print(f"bench: ranks still running after {deadline_s:.0f} s; stopping them", file=sys.stderr, flush=True)
+            break
+        time.sleep(0.05)
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        p.terminate()
+    t_kill = time.monotonic() + 5.0
+    for p in live:
+        try:
+            p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return rc if rc > 0 else 1
 
 
 def fake_sampler(local_batch, chain0, C=4, S=4):
@@ -237,6 +264,9 @@ def main():
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if fake and os.environ.get("LDM_BENCH_FAKE_FAIL_RANK") == str(rank):
+        # rehearsal of a rank that dies after joining the group: the others then wait in their first collective
+        sys.exit(3)
 
     import diffusionmodel_amd as A
     S = args.spatial
@@ -322,6 +352,9 @@ def main():
                                    f"[{B},{cfg.in_channels},{S},{S}] on rank 0, hipGraph={not args.no_graph}",
                        "global_batch": global_batch, "per_gpu_batch": B, "spatial": S,
                        "parallelism": f"dp{world} (batch-sharded chains, one all-gather of final latents)"},
+            # what the process group itself reports (None without one): shows that RCCL saw every rank of an N > 1 run
+            "collective_backend": dist.get_backend() if use_pg else None,
+            "rccl_ranks": dist.get_world_size() if use_pg else None,
             "unet_steps_per_sec": unet_steps_per_s,
             "unet_tflops": flop_step * unet_steps_per_s / 1e12,
             "unet_frac_of_mfma_peak": flop_step * unet_steps_per_s / 1e12 / peak,
