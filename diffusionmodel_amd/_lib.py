@@ -36,6 +36,10 @@ SIGNATURES = {
     "ldm_module_destroy": (None, [_vp]),
     "ldm_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_resblock_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ldm_unet_forward_train": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _u64, _vp, _vp, _vp]),
+    "ldm_resblock_forward_train": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldm_batchnorm_ws_floats": (_l, [_i, _l, _i]),
+    "ldm_batchnorm_act": (_i, [_i, _vp, _vp, _vp, _i, _l, _i, _vp, _vp, C.c_float, _i, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
     "ldm_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldm_time_addition_forward": (_i, [_vp, _vp, _vp, _i, _vp]),
     "ldm_add_noise_coefficients": (_i, [_i, _fp]),

@@ -189,6 +189,20 @@ int launch_finite_check(const float* z, long n, int* flag, hipStream_t s);
 // sinusoidal embedding of integer timesteps (src/main.rs:309-335)
 int launch_sin_embed(const int* t, int rows, int dim, float* out, hipStream_t s);
 
+// Training-mode BatchNorm on NHWC tensors (batch statistics; src/main.rs:340-341, 356, 366 on the autodiff backend).
+struct BnPlan { int G = 0, rows = 0, R = 0, nblk = 0; long pix_per_blk = 0; };
+int bn_plan(int dtype, long P, int C, BnPlan* pl);
+// floats of workspace for a tensor of P pixels x C channels: the slices' partial statistics, then 4 floats per channel
+long bn_ws_floats(int dtype, long P, int C);
+// batch mean and biased variance per channel of h [B][HW][C] (two launches, fixed summation order) -> ws;
+// mean_out / var_out [C] optional
+int launch_bn_stats(int dtype, const void* h, int B, long HW, int C, const float* gamma, const float* beta, float eps,
+                    float* ws, float* mean_out, float* var_out, hipStream_t s);
+// out = dropout(act(((h - mean) / sqrt(var + eps)) * gamma + beta + res) + tvec[b]) with the statistics launch_bn_stats
+// left in ws; out may be h
+int launch_bn_apply(int dtype, const void* h, const void* res, void* out, int B, long HW, int C, const float* ws, int act,
+                    const float* tvec, int t_img_stride, float keep_prob, unsigned long long seed, hipStream_t s);
+
 struct SchedArgs {
     float* z;              // [n] f32 state, updated in place
     const void* eps;       // [n] f32 or bf16 (eps_dtype)

@@ -221,6 +221,10 @@ struct ResBlockP {
     PackedConv c1, c2;
     int C = 0;
     int tv_off = 0;   // offset of this block's time vector inside a row of the time-vector table
+    // training mode (batch statistics): the two convolutions WITHOUT their BatchNorm folded in, and the affine
+    // parameters of bn1 / bn2 as device arrays [C]; packed on the first training-mode forward
+    PackedConv c1_raw, c2_raw;
+    float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
 struct AttnP {
     PackedConv qkv, out;
@@ -235,6 +239,7 @@ struct UnetBufs {   // NHWC activation buffers of one forward at fixed (B, H, W)
     void *a3 = nullptr, *b3 = nullptr, *c3 = nullptr, *qkv3 = nullptr, *att3 = nullptr;
     void *qkv2 = nullptr, *att2 = nullptr;
     float *sinemb = nullptr, *h1 = nullptr, *temb = nullptr, *tvec = nullptr;   // time path, `rows` rows
+    float* bn_ws = nullptr;   // training mode: workspace of the batch-statistics kernels (largest level)
     size_t bytes = 0;
 };
 
@@ -261,7 +266,8 @@ struct ldm_module {
     int kind = 0, dtype = 0, in_ch = 0, te = 0;
     int ch[3] = {64, 128, 256};
     bool scaled = false, finalized = false;
-    std::map<std::string, std::vector<float>> params;
+    bool train_ready = false;   // the ResidualBlocks' unfolded convolutions are packed (first training-mode forward)
+    std::map<std::string, std::vector<float>> params;   // after finalize: only what a training-mode forward still needs
     std::map<std::string, std::pair<std::vector<float>, std::vector<float>>> composed;   // compose_up results, until finalize ends
     DevPool pool;
     // packed network
@@ -785,9 +791,46 @@ static int finalize_module(ldm_module* m) {
         LDM_REQUIRE(m->out_conv.cout == m->clp, "internal: padded output and padded latent widths differ");
         LDM_TRY(pack_dense4(m, wt, bt));
     }
-    m->params.clear();
+    // A training-mode forward (batch statistics) needs the ResidualBlocks' convolutions without the BatchNorm folded
+    // in and the affine parameters: those host arrays stay until that forward has packed them; all others go now.
+    for (auto it = m->params.begin(); it != m->params.end();) {
+        const std::string& k = it->first;
+        const bool keep = (m->kind == LDM_MOD_UNET || m->kind == LDM_MOD_RESBLOCK) &&
+                          (k.find("conv1.") != std::string::npos || k.find("conv2.") != std::string::npos ||
+                           k.find("bn1.gamma") != std::string::npos || k.find("bn1.beta") != std::string::npos ||
+                           k.find("bn2.gamma") != std::string::npos || k.find("bn2.beta") != std::string::npos) &&
+                          k.find("up_conv") == std::string::npos;
+        if (keep) ++it;
+        else it = m->params.erase(it);
+    }
     m->composed.clear();
     m->finalized = true;
+    return LDM_OK;
+}
+
+// The ResidualBlocks as a training-mode forward runs them: conv1 / conv2 with their own bias only, gamma / beta of
+// bn1 / bn2 on the device.  Runs once per module, on the first training-mode forward (host packing + uploads).
+static int ensure_train_pack(ldm_module* m) {
+    if (m->train_ready) return LDM_OK;
+    LDM_REQUIRE(m->kind == LDM_MOD_UNET || m->kind == LDM_MOD_RESBLOCK, "training mode needs a UNet or ResidualBlock module");
+    const int nb = m->kind == LDM_MOD_UNET ? 7 : 1;
+    for (int i = 0; i < nb; ++i) {
+        ResBlockP& rp = m->rb[i];
+        const std::string pre = m->kind == LDM_MOD_UNET ? kResNames[i] : "";
+        LDM_TRY(pack_conv3x3(m, pjoin(pre, "conv1"), "", rp.C, rp.C, 1, &rp.c1_raw));
+        LDM_TRY(pack_conv3x3(m, pjoin(pre, "conv2"), "", rp.C, rp.C, 1, &rp.c2_raw));
+        const std::vector<float>*g1, *b1, *g2, *b2;
+        LDM_TRY(get_param(m, pjoin(pre, "bn1.gamma"), rp.C, &g1));
+        LDM_TRY(get_param(m, pjoin(pre, "bn1.beta"), rp.C, &b1));
+        LDM_TRY(get_param(m, pjoin(pre, "bn2.gamma"), rp.C, &g2));
+        LDM_TRY(get_param(m, pjoin(pre, "bn2.beta"), rp.C, &b2));
+        LDM_TRY(m->pool.upload((void**)&rp.g1, g1->data(), g1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&rp.be1, b1->data(), b1->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&rp.g2, g2->data(), g2->size() * 4));
+        LDM_TRY(m->pool.upload((void**)&rp.be2, b2->data(), b2->size() * 4));
+    }
+    m->params.clear();
+    m->train_ready = true;
     return LDM_OK;
 }
 
@@ -825,6 +868,35 @@ static int run_resblock(const ResBlockP& rp, const void* x, void* tmp, void* out
     return LDM_OK;
 }
 
+// Training-mode forward (batch statistics, active dropout): what DiffusionModel::forward runs on the autodiff
+// backend (src/main.rs:635-679, :1318).
+struct TrainCtx {
+    float* bn_ws = nullptr;          // workspace of the statistics kernels
+    float* bn_mean = nullptr;        // optional exports [2 * tv_total]: per block bn1 then bn2
+    float* bn_var = nullptr;
+    float keep_prob = 1.0f;          // mid_drop: 1 - p (1: no dropout)
+    unsigned long long seed = 0;
+};
+constexpr float kBnEps = 1e-5f;      // burn's BatchNormConfig default
+
+// ResidualBlock::forward with bn1 / bn2 on the statistics of the batch (src/main.rs:372-387):
+//   tmp = conv1(x); tmp <- silu(bn1(tmp)) + t;   out = conv2(tmp); out <- dropout(silu(bn2(out) + x))
+static int run_resblock_train(const ResBlockP& rp, int dtype, const void* x, void* tmp, void* out, int B, int H, int W,
+                              const TimeVec& tv, const TrainCtx& tc, float keep_prob, hipStream_t st) {
+    const long HW = (long)H * W;
+    float* m1 = tc.bn_mean ? tc.bn_mean + 2 * rp.tv_off : nullptr;
+    float* v1 = tc.bn_var ? tc.bn_var + 2 * rp.tv_off : nullptr;
+    LDM_TRY(run_conv(rp.c1_raw, x, rp.C, nullptr, 0, tmp, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(launch_bn_stats(dtype, tmp, B, HW, rp.C, rp.g1, rp.be1, kBnEps, tc.bn_ws, m1, v1, st));
+    LDM_TRY(launch_bn_apply(dtype, tmp, nullptr, tmp, B, HW, rp.C, tc.bn_ws, ACT_SILU, tv.table + rp.tv_off, tv.img_stride,
+                            1.0f, 0, st));
+    LDM_TRY(run_conv(rp.c2_raw, tmp, rp.C, nullptr, 0, out, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    LDM_TRY(launch_bn_stats(dtype, out, B, HW, rp.C, rp.g2, rp.be2, kBnEps, tc.bn_ws, m1 ? m1 + rp.C : nullptr,
+                            v1 ? v1 + rp.C : nullptr, st));
+    LDM_TRY(launch_bn_apply(dtype, out, x, out, B, HW, rp.C, tc.bn_ws, ACT_SILU, nullptr, 0, keep_prob, tc.seed, st));
+    return LDM_OK;
+}
+
 // Attention::forward (src/main.rs:256-276): qkv projection, soft-max attention, out projection + x
 static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, void* att, void* out, int B, int H, int W,
                          hipStream_t st) {
@@ -837,7 +909,7 @@ static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, v
 }
 
 static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_rows, char* base, UnetBufs* ub,
-                             int tv_total = -1) {
+                             int tv_total = -1, bool train = false) {
     if (tv_total < 0) tv_total = m->tv_total;
     const size_t es = es_of(m->dtype);
     const size_t p1 = (size_t)B * H * W, p2 = p1 / 4, p3 = p1 / 16;
@@ -859,6 +931,15 @@ static size_t plan_unet_bufs(const ldm_module* m, int B, int H, int W, int time_
     ub->h1 = (float*)take((size_t)time_rows * m->te * 8 * 4);
     ub->temb = (float*)take((size_t)time_rows * m->te * 4);
     ub->tvec = (float*)take((size_t)time_rows * tv_total * 4);
+    if (train) {
+        long w = 0;
+        const long ps[3] = {(long)p1, (long)p2, (long)p3};
+        for (int l = 0; l < 3; ++l) {
+            const long f = bn_ws_floats(m->dtype, ps[l], m->ch[l]);
+            if (f > w) w = f;
+        }
+        ub->bn_ws = (float*)take((size_t)(w > 0 ? w : 4) * 4);
+    }
     ub->bytes = off;
     return off;
 }
@@ -885,9 +966,15 @@ struct DdimFuse {
 };
 
 static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int B, int H, int W,
-                         const TimeVec& tv, hipStream_t st, const DdimFuse* ddim = nullptr) {
+                         const TimeVec& tv, hipStream_t st, const DdimFuse* ddim = nullptr, const TrainCtx* train = nullptr) {
     const int c1 = m->ch[0], c2 = m->ch[1], c3 = m->ch[2];
     const int H2 = H / 2, W2 = W / 2, H3 = H / 4, W3 = W / 4;
+    // one ResidualBlock, in the mode of this forward; `drop` = this block's output goes through mid_drop
+    auto run_resblock = [&](const ResBlockP& rp, const void* x, void* tmp, void* out, int b, int h, int w, const TimeVec& t,
+                            hipStream_t s2, bool drop = false) {
+        if (train) return run_resblock_train(rp, m->dtype, x, tmp, out, b, h, w, t, *train, drop ? train->keep_prob : 1.0f, s2);
+        return ::run_resblock(rp, x, tmp, out, b, h, w, t, s2);
+    };
     LDM_TRY(run_conv(m->down1, xin, m->clp, nullptr, 0, ub.a1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_resblock(m->rb[0], ub.a1, ub.b1, ub.s1, B, H, W, tv, st));                 // down_1 = s1
     LDM_TRY(run_conv(m->down2, ub.s1, c1, nullptr, 0, ub.a2, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
@@ -896,7 +983,7 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
     LDM_TRY(run_resblock(m->rb[2], ub.a3, ub.b3, ub.c3, B, H3, W3, tv, st));               // down_3 = c3
     LDM_TRY(run_resblock(m->rb[3], ub.c3, ub.b3, ub.a3, B, H3, W3, tv, st));               // mid_res1 -> a3
     LDM_TRY(run_attention(m->mid_atten, m->dtype, ub.a3, ub.qkv3, ub.att3, ub.b3, B, H3, W3, st));   // -> b3
-    LDM_TRY(run_resblock(m->rb[4], ub.b3, ub.c3, ub.a3, B, H3, W3, tv, st));               // mid_res2 -> a3
+    LDM_TRY(run_resblock(m->rb[4], ub.b3, ub.c3, ub.a3, B, H3, W3, tv, st, true));         // mid_res2 (+ mid_drop) -> a3
     if (m->have_up_fused) {
         // up1 + cat + up_conv1 as one transposed conv over {a3, skip s2} -> b2
         LDM_TRY(run_conv(m->up1_fused, ub.a3, c3, ub.s2, c2, ub.b2, B, H3, W3, ACT_NONE, nullptr, nullptr, 0, 0, st));
@@ -1220,6 +1307,73 @@ int ldm_unet_forward(ldm_module* m, const float* x, const float* time_emb, float
     LDM_TRY(run_unet_body(m, ub, ub.xin, ub.eps, B, H, W, tv, st));
     LDM_TRY(launch_nhwc_to_nchw(ub.eps, LDM_F32, eps, B, m->in_ch, m->out_conv.cout, H, W, st));
     return LDM_OK;
+}
+
+// Unet::forward as DiffusionModel::forward runs it (src/main.rs:655 on the autodiff backend, :1318): BatchNorm on the
+// statistics of the batch, mid_drop active.  Always the tiled kernels (the whole-image matrices of 4x4 latents have
+// the running statistics folded in).
+int ldm_unet_forward_train(ldm_module* m, const float* x, const float* time_emb, float* eps, int B, int H, int W,
+                           float dropout_p, unsigned long long dropout_seed, float* bn_mean, float* bn_var, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_UNET && m->finalized, "needs a finalized UNet module");
+    LDM_REQUIRE(x && time_emb && eps, "null tensor");
+    LDM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "H and W must be positive multiples of 4");
+    LDM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout probability must be in [0, 1)");
+    hipStream_t st = (hipStream_t)stream;
+    LDM_TRY(ensure_train_pack(m));
+    UnetBufs ub;
+    const size_t need = plan_unet_bufs(m, B, H, W, B, nullptr, &ub, -1, true);
+    LDM_TRY(ensure_ws(m, need));
+    plan_unet_bufs(m, B, H, W, B, (char*)m->ws, &ub, -1, true);
+    LDM_TRY(run_time_path(m, time_emb, B, ub, st));
+    LDM_TRY(launch_nchw_to_nhwc(x, ub.xin, m->dtype, B, m->in_ch, m->clp, H, W, st));
+    TimeVec tv;
+    tv.table = ub.tvec; tv.img_stride = m->tv_total;
+    TrainCtx tc;
+    tc.bn_ws = ub.bn_ws; tc.bn_mean = bn_mean; tc.bn_var = bn_var;
+    tc.keep_prob = 1.0f - dropout_p; tc.seed = dropout_seed;
+    LDM_TRY(run_unet_body(m, ub, ub.xin, ub.eps, B, H, W, tv, st, nullptr, &tc));
+    LDM_TRY(launch_nhwc_to_nchw(ub.eps, LDM_F32, eps, B, m->in_ch, m->out_conv.cout, H, W, st));
+    return LDM_OK;
+}
+
+int ldm_resblock_forward_train(ldm_module* m, const float* x, const float* t_emb, float* out, int B, int H, int W,
+                               float* bn_mean, float* bn_var, void* stream) {
+    LDM_REQUIRE(m && m->kind == LDM_MOD_RESBLOCK && m->finalized, "needs a finalized ResidualBlock module");
+    LDM_REQUIRE(x && t_emb && out && B > 0 && H > 0 && W > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    LDM_TRY(ensure_train_pack(m));
+    const size_t es = es_of(m->dtype), C = m->in_ch;
+    const size_t act = align_up((size_t)B * H * W * C * es, 256);
+    const long wsf = bn_ws_floats(m->dtype, (long)B * H * W, (int)C);
+    LDM_REQUIRE(wsf > 0, "channel count not served by the batch-statistics kernels");
+    const size_t tvb = align_up((size_t)B * C * 4, 256);
+    LDM_TRY(ensure_ws(m, 3 * act + tvb + (size_t)wsf * 4));
+    char* base = (char*)m->ws;
+    void *xin = base, *tmp = base + act, *o = base + 2 * act;
+    float* tvec = (float*)(base + 3 * act);
+    TrainCtx tc;
+    tc.bn_ws = (float*)(base + 3 * act + tvb); tc.bn_mean = bn_mean; tc.bn_var = bn_var;
+    LDM_TRY(launch_linear_f32(t_emb, m->twt, m->tbt, tvec, B, m->te, (int)C, ACT_SILU, st));
+    LDM_TRY(launch_nchw_to_nhwc(x, xin, m->dtype, B, (int)C, (int)C, H, W, st));
+    TimeVec tv;
+    tv.table = tvec; tv.img_stride = (int)C;
+    LDM_TRY(run_resblock_train(m->rb[0], m->dtype, xin, tmp, o, B, H, W, tv, tc, 1.0f, st));
+    LDM_TRY(launch_nhwc_to_nchw(o, m->dtype, out, B, (int)C, (int)C, H, W, st));
+    return LDM_OK;
+}
+
+long ldm_batchnorm_ws_floats(int dtype, long pixels, int channels) { return bn_ws_floats(dtype, pixels, channels); }
+
+int ldm_batchnorm_act(int dtype, const void* h, const void* res, void* out, int B, long HW, int C, const float* gamma,
+                      const float* beta, float eps, int act, const float* tvec, float dropout_p, unsigned long long seed,
+                      float* ws, float* mean_out, float* var_out, void* stream) {
+    LDM_REQUIRE(dtype == LDM_F32 || dtype == LDM_BF16, "unknown dtype");
+    LDM_REQUIRE(act >= ACT_NONE && act <= ACT_RELU, "unknown activation");
+    LDM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout probability must be in [0, 1)");
+    hipStream_t st = (hipStream_t)stream;
+    LDM_TRY(launch_bn_stats(dtype, h, B, HW, C, gamma, beta, eps, ws, mean_out, var_out, st));
+    if (!out) return LDM_OK;    // statistics only
+    return launch_bn_apply(dtype, h, res, out, B, HW, C, ws, act, tvec, C, 1.0f - dropout_p, seed, st);
 }
 
 int ldm_resblock_forward(ldm_module* m, const float* x, const float* t_emb, float* out, int B, int H, int W, void* stream) {

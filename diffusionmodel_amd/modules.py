@@ -143,15 +143,25 @@ class ResiduelBlock(_Module):
         super().__init__(_lib.LDM_MOD_RESBLOCK, dtype, channels, time_embed,
                          resblock_param_shapes(channels, time_embed), weights, seed)
 
-    def forward(self, x: torch.Tensor, time_embed: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, time_embed: torch.Tensor, train: bool = False, return_stats: bool = False):
+        """train=True: bn1 / bn2 normalise with the statistics of the batch, as on the reference's autodiff backend
+        (src/main.rs:1318); return_stats adds the batch (mean, var), each [2 * channels]: bn1 then bn2."""
         x = _dev_f32(x, "x")
         if x.dim() != 4 or x.shape[1] != self.channels:
             raise ValueError(f"x must be [B, {self.channels}, H, W]")
         B, _, H, W = x.shape
         t = _dev_f32(time_embed, "time_embed", (B, self.time_embed))
         out = torch.empty_like(x)
-        _lib.check(self._lib.ldm_resblock_forward(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, _stream()))
-        return out
+        if not train:
+            _lib.check(self._lib.ldm_resblock_forward(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, _stream()))
+            return out
+        mean = var = None
+        if return_stats:
+            mean = torch.empty(2 * self.channels, dtype=torch.float32, device=x.device)
+            var = torch.empty_like(mean)
+        _lib.check(self._lib.ldm_resblock_forward_train(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, _ptr(mean), _ptr(var),
+                                                        _stream()))
+        return (out, mean, var) if return_stats else out
 
 
 ResidualBlock = ResiduelBlock
@@ -170,15 +180,30 @@ class UNet(_Module):
         super().__init__(_lib.LDM_MOD_UNET, dtype, in_channels, time_embed_dim, unet_param_shapes(self.cfg), weights,
                          seed, channels=channels, scaled_attention=scaled_attention)
 
-    def forward(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, time: torch.Tensor, train: bool = False, dropout_p: float = 0.5,
+                dropout_seed: int = 0, return_stats: bool = False):
+        """train=False: inference semantics (running statistics folded into the convolutions, no dropout).
+        train=True: the forward of the reference's training step (autodiff backend, src/main.rs:1318): every
+        ResidualBlock's BatchNorm on the statistics of the batch, mid_drop (p = 0.5, :458) active with a mask from the
+        counter-based generator keyed by dropout_seed; return_stats adds the batch (mean, var) of the fourteen
+        BatchNorms, each [2 * sum of block channels] in block order, bn1 then bn2."""
         x = _dev_f32(x, "x")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"x must be [B, {self.in_channels}, H, W]")
         B, _, H, W = x.shape
         t = _dev_f32(time, "time", (B, self.time_embed_dim))
         out = torch.empty_like(x)
-        _lib.check(self._lib.ldm_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, _stream()))
-        return out
+        if not train:
+            _lib.check(self._lib.ldm_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, _stream()))
+            return out
+        mean = var = None
+        if return_stats:
+            c1, c2, c3 = self.cfg.channels
+            mean = torch.empty(2 * (2 * c1 + 2 * c2 + 3 * c3), dtype=torch.float32, device=x.device)
+            var = torch.empty_like(mean)
+        _lib.check(self._lib.ldm_unet_forward_train(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(dropout_p),
+                                                    dropout_seed & (2 ** 64 - 1), _ptr(mean), _ptr(var), _stream()))
+        return (out, mean, var) if return_stats else out
 
 
 Unet = UNet
@@ -296,8 +321,9 @@ class DiffusionModel:
         return torch.from_numpy(schedule.ddim_coefficients(self.num_time, steps))
 
     # -- network --------------------------------------------------------------------------------
-    def noise_predict(self, x_t: torch.Tensor, time_emb: torch.Tensor) -> torch.Tensor:
-        return self.unet.forward(x_t, time_emb)
+    def noise_predict(self, x_t: torch.Tensor, time_emb: torch.Tensor, train: bool = False, dropout_p: float = 0.5,
+                      dropout_seed: int = 0) -> torch.Tensor:
+        return self.unet.forward(x_t, time_emb, train=train, dropout_p=dropout_p, dropout_seed=dropout_seed)
 
     # -- forward process and loss value (the step before the path in training; no backward here) ----
     def add_noise(self, x: torch.Tensor, time: torch.Tensor, noise: Optional[torch.Tensor] = None):
@@ -322,11 +348,15 @@ class DiffusionModel:
         return out, noise
 
     def forward(self, z: torch.Tensor, time: Optional[torch.Tensor] = None,
-                noise: Optional[torch.Tensor] = None, check_finite: bool = False) -> torch.Tensor:
+                noise: Optional[torch.Tensor] = None, check_finite: bool = False, train: bool = True,
+                dropout_p: float = 0.5, dropout_seed: int = 0) -> torch.Tensor:
         """The loss value of DiffusionModel::forward (src/main.rs:635-679) from the latent on: random
         timesteps (or `time`), add_noise, sinusoidal embedding, noise prediction, mean squared error.
         z is what the reference obtains from vae.encode(x).detach() (:636; the encoder stays with the
         reference).  Returns a tensor of shape [1].  Value only: there is no backward pass here.
+        train=True (the default: the reference only ever calls this on its autodiff backend, :1318, :1554) predicts
+        the noise with batch-statistics BatchNorm and mid_drop active (mask keyed by dropout_seed); train=False
+        evaluates the same loss with the sampler's inference semantics.
         check_finite: the reference's three probes (:647-651, 657-662, 672-676): a noisy latent, a prediction or a
         loss that is not finite gives the sentinel loss 100.0 (each probe reads a flag back, as the reference's do)."""
         z = _dev_f32(z, "z")
@@ -338,7 +368,7 @@ class DiffusionModel:
         if check_finite and not latent_is_finite(z_noisy):
             return sentinel()
         t_emb = sin_time_addition(time.to(z.device), self.time_embed_dim)
-        pred = self.noise_predict(z_noisy, t_emb)
+        pred = self.noise_predict(z_noisy, t_emb, train=train, dropout_p=dropout_p, dropout_seed=dropout_seed)
         if check_finite and not latent_is_finite(pred):
             return sentinel()
         ws = torch.empty(1024, dtype=torch.float32, device=z.device)

@@ -80,3 +80,40 @@ class ConvOp:
         return out
 
     __call__ = forward
+
+
+def batchnorm_act(h: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: Optional[str] = None,
+                  res: Optional[torch.Tensor] = None, tvec: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                  dropout_p: float = 0.0, seed: int = 0, out: Optional[torch.Tensor] = None, stats_only: bool = False):
+    """Training-mode BatchNorm + the ResidualBlock's tail on a contiguous NHWC device tensor h [B,H,W,C] (bf16 or
+    f32): out = dropout(act(((h - mean) / sqrt(var + eps)) * gamma + beta + res) + tvec[b]) with the batch
+    statistics of h (ldm_batchnorm_act; burn's BatchNorm on the autodiff backend, src/main.rs:374, 385, 1318).
+    Returns (out, mean, var); out is None with stats_only."""
+    if not (h.is_cuda and h.is_contiguous() and h.dim() == 4 and h.dtype in (torch.bfloat16, torch.float32)):
+        raise ValueError("h must be a contiguous NHWC device tensor, bf16 or f32")
+    B, H, W, Cc = h.shape
+    code = _lib.LDM_BF16 if h.dtype == torch.bfloat16 else _lib.LDM_F32
+    lib = _lib.load()
+    g = gamma.detach().to(h.device, torch.float32).contiguous()
+    b = beta.detach().to(h.device, torch.float32).contiguous()
+    if g.numel() != Cc or b.numel() != Cc:
+        raise ValueError("gamma and beta must hold one value per channel")
+    nws = lib.ldm_batchnorm_ws_floats(code, B * H * W, Cc)
+    if nws <= 0:
+        raise ValueError("channel count not served")
+    ws = torch.empty(nws, dtype=torch.float32, device=h.device)
+    mean = torch.empty(Cc, dtype=torch.float32, device=h.device)
+    var = torch.empty(Cc, dtype=torch.float32, device=h.device)
+    if res is not None and not (res.is_contiguous() and res.dtype == h.dtype and tuple(res.shape) == tuple(h.shape)):
+        raise ValueError("res must match h")
+    if tvec is not None:
+        tvec = tvec.detach().to(h.device, torch.float32).contiguous()
+        if tuple(tvec.shape) != (B, Cc):
+            raise ValueError("tvec must be [B, C]")
+    if not stats_only and out is None:
+        out = torch.empty_like(h)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+    _lib.check(lib.ldm_batchnorm_act(code, p(h), p(res), p(None if stats_only else out), B, H * W, Cc, p(g), p(b), eps,
+                                     ACTS[act], p(tvec), dropout_p, seed & (2 ** 64 - 1), p(ws), p(mean), p(var), stream))
+    return (None if stats_only else out), mean, var

@@ -97,6 +97,41 @@ int ldm_attention_forward(ldm_module* m, const float* x_dev, float* out_dev, int
 /* TimeAddition::forward(t), src/main.rs:302-306.  t/out [B,dim]. */
 int ldm_time_addition_forward(ldm_module* m, const float* t_dev, float* out_dev, int B, void* stream);
 
+/* ---- training-mode forward: the noise prediction as DiffusionModel::forward computes it -------- */
+/* DiffusionModel::forward (src/main.rs:635-679) runs Unet::forward on the autodiff backend (:1318), where burn's
+ * BatchNorm (bn1 / bn2 of every ResidualBlock, :340-341, 356, 366, 374, 385) normalises with the statistics of the
+ * batch -- per channel the mean and the biased variance over (B, H, W), eps 1e-5 -- and mid_drop (:403, 458, 513)
+ * zeroes each element with probability dropout_p (the reference's 0.5) and scales the rest by 1 / (1 - dropout_p).
+ * Forward value only: no gradients, and the modules' running statistics are not touched.
+ * time_emb [B, time_embed_dim]: one sinusoidal row per image (the reference draws a timestep per image, :639-653).
+ * The dropout mask comes from the library's counter-based generator: element (b, c, y, x) of the
+ * [B, C, H/4, W/4] tensor is kept when word (c & 3) of Philox-4x32-10 with counter
+ * {((y W/4 + x) C + c) / 4, 0xFFFFFFFE, b, 0x4C444D32} and key dropout_seed gives ((word >> 8) + 0.5) 2^-24 < 1 - p.
+ * bn_mean_dev / bn_var_dev: optional [2 * (sum of the seven blocks' channels)] f32, per block (down_res1,
+ * down_res2, down_res3, mid_res1, mid_res2, up_res1, up_res2) bn1's channels then bn2's: the batch statistics, from
+ * which the caller can make burn's running-average update (momentum 0.1).
+ * The first training-mode call on a module packs the unfolded convolutions (host work and device allocations). */
+int ldm_unet_forward_train(ldm_module* m, const float* x_dev, const float* time_emb_dev, float* eps_dev, int B, int H, int W,
+                           float dropout_p, unsigned long long dropout_seed, float* bn_mean_dev, float* bn_var_dev,
+                           void* stream);
+/* ResidualBlock::forward (src/main.rs:372-387) with bn1 / bn2 on the statistics of the batch.
+ * bn_mean_dev / bn_var_dev: optional [2 * channels] (bn1 then bn2). */
+int ldm_resblock_forward_train(ldm_module* m, const float* x_dev, const float* t_emb_dev, float* out_dev, int B, int H, int W,
+                               float* bn_mean_dev, float* bn_var_dev, void* stream);
+/* Kernel-level operator behind both: training-mode BatchNorm + the ResidualBlock's tail on an NHWC tensor of `dtype`
+ * elements, h [B, HW, C] (C a multiple of 8 in bf16, of 4 in f32; 16-byte aligned):
+ *   out = dropout(act(((h - mean) / sqrt(var + eps)) * gamma + beta + res) + tvec[b, :])
+ * mean / var = per-channel batch statistics of h (biased variance; a two-stage sum in a fixed order, so the result
+ * does not depend on scheduling).  res [B, HW, C] or NULL; tvec [B, C] f32 or NULL; out may be h, or NULL for the
+ * statistics alone; act: 0 none, 1 SiLU, 2 ReLU; ws_dev: ldm_batchnorm_ws_floats(dtype, B * HW, C) floats;
+ * mean_out_dev / var_out_dev [C] optional.  The dropout mask is the one described above with (H/4, W/4) = the
+ * tensor's own pixels. */
+long ldm_batchnorm_ws_floats(int dtype, long pixels, int channels);
+int ldm_batchnorm_act(int dtype, const void* h_dev, const void* res_dev, void* out_dev, int B, long HW, int C,
+                      const float* gamma_dev, const float* beta_dev, float eps, int act, const float* tvec_dev,
+                      float dropout_p, unsigned long long seed, float* ws_dev, float* mean_out_dev, float* var_out_dev,
+                      void* stream);
+
 /* ---- the step after the loop: Vae::decode and the 8-bit image ------------------------------- */
 /* SimpleDecoder::new(output, latent_dimen), src/main.rs:108-147.  The module takes its parameters through
  * ldm_module_set_param / ldm_module_finalize / ldm_module_destroy like the others: "transfer.weight"

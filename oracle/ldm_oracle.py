@@ -16,7 +16,11 @@ Decisions that the reference leaves open (its Unet::forward cannot run as writte
       (src/main.rs:432,443,502,506) are skipped, which is the only pyramid consistent with the two
       x2 transposed convolutions and both skip concatenations (src/main.rs:515-516,520-521).
   D2  attention follows the Rust statement (softmax over keys, out-projection applied).
-  D3  inference semantics: BatchNorm uses running statistics, Dropout is the identity.
+  D3  the SAMPLER has inference semantics: BatchNorm uses running statistics, Dropout is the identity.  The training
+      forward (DiffusionModel::forward, src/main.rs:635-679, only ever run on the autodiff backend, :1318) is stated
+      with `train=True`: batch-statistics BatchNorm and active Dropout, following burn 0.18.0's published
+      BatchNorm::forward_train / Dropout::forward (burn-core nn/norm/batch.rs, nn/dropout.rs; a Cargo.lock dependency
+      whose source is not in /root/reference, so this part is restated from the published algorithm).
   D4  BatchNorm eps = 1e-5 (burn default).
   D5  the per-step NaN probes (src/main.rs:706-710,725-729,759-763) are not reproduced.
   D7  "scaled" UNet = same topology with wider channels plus one extra Attention after up_res1.
@@ -89,18 +93,66 @@ def batch_norm(p, name: str, x):
     return (x - m) / torch.sqrt(v + BN_EPS) * g + b
 
 
+def batch_norm_train(p, name: str, x, stats: Optional[dict] = None):
+    """burn 0.18 BatchNorm::forward_train (the branch taken when the backend has autodiff enabled): per channel
+    mean over (B, H, W), var = mean of (x - mean)^2 over the same elements (biased), then forward_shared:
+    ((x - mean) / sqrt(var + eps)) * gamma + beta.  The running statistics are updated as a side effect there
+    (running = running * (1 - 0.1) + batch * 0.1); here the batch statistics are recorded in `stats[name]`."""
+    mean = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+    if stats is not None:
+        stats[name] = (mean.reshape(-1).clone(), var.reshape(-1).clone())
+    g = p[name + ".gamma"].to(x.dtype).reshape(1, -1, 1, 1)
+    b = p[name + ".beta"].to(x.dtype).reshape(1, -1, 1, 1)
+    return (x - mean) / torch.sqrt(var + BN_EPS) * g + b
+
+
+DROPOUT_TAG = 0x4C444D32
+DROPOUT_STEP = 0xFFFFFFFE
+
+
+def dropout_mask_nchw(seed: int, B: int, C: int, H: int, W: int, keep_prob: float) -> torch.Tensor:
+    """The keep mask of the build's dropout, [B, C, H, W] of 0 / 1 (f32).  burn's Dropout::forward draws
+    Bernoulli(1 - p) from the backend's RNG (unreproducible); the build draws it from the counter-based generator so
+    that both sides can hold the same mask: element (b, c, y, x) is kept when word (c % 4) of Philox-4x32-10 with
+    counter {((y W + x) C + c) // 4, DROPOUT_STEP, b, DROPOUT_TAG} and key (seed low, seed high) gives
+    ((word >> 8) + 0.5) * 2^-24 < keep_prob."""
+    assert C % 4 == 0
+    G = H * W * C // 4
+    g = np.arange(G, dtype=np.uint32)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    out = np.empty((B, H, W, C), dtype=np.float32)
+    for b in range(B):
+        ctr = np.stack([g, np.full(G, DROPOUT_STEP, np.uint32), np.full(G, b, np.uint32),
+                        np.full(G, DROPOUT_TAG, np.uint32)], axis=-1)
+        r = philox4x32_10(ctr, key)
+        u = ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+        out[b] = (u < np.float32(keep_prob)).astype(np.float32).reshape(H, W, C)
+    return torch.from_numpy(out).permute(0, 3, 1, 2).contiguous()
+
+
+def dropout(x, prob: float, seed: int):
+    """burn 0.18 Dropout::forward with autodiff enabled: x * Bernoulli(1 - prob) * (1 / (1 - prob))."""
+    if prob == 0.0:
+        return x
+    keep = 1.0 - prob
+    mask = dropout_mask_nchw(seed, x.shape[0], x.shape[1], x.shape[2], x.shape[3], keep).to(x.dtype)
+    return x * mask * (1.0 / keep)
+
+
 # --------------------------------------------------------------------------------------------
 # a3-a5  ResidualBlock                                               src/main.rs:372-387
 # --------------------------------------------------------------------------------------------
-def residual_block(p, prefix: str, x, t_emb):
+def residual_block(p, prefix: str, x, t_emb, train: bool = False, stats: Optional[dict] = None):
+    bn = (lambda name, h: batch_norm_train(p, name, h, stats)) if train else (lambda name, h: batch_norm(p, name, h))
     h = conv2d(p, prefix + ".conv1", x, 1, 1)
-    h = batch_norm(p, prefix + ".bn1", h)
+    h = bn(prefix + ".bn1", h)
     h = F.silu(h)
     t = linear(p, prefix + ".time", t_emb)
     t = F.silu(t)
     h = h + t.reshape(t.shape[0], t.shape[1], 1, 1)
     h = conv2d(p, prefix + ".conv2", h, 1, 1)
-    h = batch_norm(p, prefix + ".bn2", h)
+    h = bn(prefix + ".bn2", h)
     return F.silu(h + x)
 
 
@@ -160,28 +212,33 @@ def to_rgb8(img) -> np.ndarray:
 # --------------------------------------------------------------------------------------------
 # Unet::forward                                                      src/main.rs:496-526 (+D1, D7)
 # --------------------------------------------------------------------------------------------
-def unet_forward(p, x, time, scaled_attention: bool = False, return_time_embed: bool = False):
+def unet_forward(p, x, time, scaled_attention: bool = False, return_time_embed: bool = False, train: bool = False,
+                 dropout_p: float = 0.5, dropout_seed: int = 0, stats: Optional[dict] = None):
+    """train=True: the forward of the training step (autodiff backend, src/main.rs:1318): BatchNorm on batch
+    statistics, mid_drop (:458, :513) active; `stats` collects {bn name: (batch mean, batch var)}."""
+    rb = lambda name, h: residual_block(p, name, h, te, train=train, stats=stats)   # noqa: E731
     te = time_addition(p, "time_emb", time)
     d1 = conv2d(p, "down1", x, 1, 1)
-    d1 = residual_block(p, "down_res1", d1, te)
+    d1 = rb("down_res1", d1)
     d2 = conv2d(p, "down2", d1, 2, 1)                    # pool1 skipped (D1)
-    d2 = residual_block(p, "down_res2", d2, te)
+    d2 = rb("down_res2", d2)
     d3 = conv2d(p, "down3", d2, 2, 1)                    # pool2 skipped (D1)
-    d3 = residual_block(p, "down_res3", d3, te)
-    m = residual_block(p, "mid_res1", d3, te)
+    d3 = rb("down_res3", d3)
+    m = rb("mid_res1", d3)
     m = attention(p, "mid_atten", m)
-    m = residual_block(p, "mid_res2", m, te)
-    # mid_drop: identity at inference (D3)
+    m = rb("mid_res2", m)
+    if train:
+        m = dropout(m, dropout_p, dropout_seed)          # mid_drop, :513; identity at inference (D3)
     u1 = conv_transpose2d(p, "up1", m, 2, 1)
     u1 = torch.cat([u1, d2], dim=1)
     u1 = conv2d(p, "up_conv1", u1, 1, 0)
-    u1 = residual_block(p, "up_res1", u1, te)
+    u1 = rb("up_res1", u1)
     if scaled_attention:
         u1 = attention(p, "up_atten", u1)                # D7
     u2 = conv_transpose2d(p, "up2", u1, 2, 1)
     u2 = torch.cat([u2, d1], dim=1)
     u2 = conv2d(p, "up_conv2", u2, 1, 0)
-    u2 = residual_block(p, "up_res2", u2, te)
+    u2 = rb("up_res2", u2)
     out = conv2d(p, "out_conv", u2, 1, 1)
     if return_time_embed:
         return out, te
@@ -369,13 +426,16 @@ def add_noise(x: torch.Tensor, time, num_time: int, noise: torch.Tensor) -> torc
     return x * sa + noise * s1m
 
 
-def diffusion_loss(p, z: torch.Tensor, time, num_time: int, noise: torch.Tensor, time_embed_dim: int = 256) -> torch.Tensor:
+def diffusion_loss(p, z: torch.Tensor, time, num_time: int, noise: torch.Tensor, time_embed_dim: int = 256,
+                   train: bool = False, dropout_p: float = 0.5, dropout_seed: int = 0, return_pred: bool = False):
     """DiffusionModel::forward from the latent on (:641-679): add_noise, sin_time_addition, noise_predict,
-    mean of the squared difference.  The NaN probes (:645-650, 657-662, 673-677) are not reproduced (D5)."""
+    mean of the squared difference.  The NaN probes (:645-650, 657-662, 673-677) are not reproduced (D5).
+    train=True is how the reference runs it (autodiff backend, :1318): batch-statistics BatchNorm, mid_drop active."""
     z_noisy = add_noise(z, time, num_time, noise)
     t_emb = sin_time_addition(torch.as_tensor(list(time)), time_embed_dim)
-    pred = unet_forward(p, z_noisy, t_emb)
-    return ((pred.flatten(1) - noise.flatten(1)) ** 2).mean().reshape(1)
+    pred = unet_forward(p, z_noisy, t_emb, train=train, dropout_p=dropout_p, dropout_seed=dropout_seed)
+    loss = ((pred.flatten(1) - noise.flatten(1)) ** 2).mean().reshape(1)
+    return (loss, pred) if return_pred else loss
 
 
 def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:

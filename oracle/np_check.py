@@ -66,6 +66,52 @@ def batch_norm(x, gamma, beta, mean, var, eps=1e-5):
         * np.asarray(gamma, np.float64).reshape(sh) + np.asarray(beta, np.float64).reshape(sh)
 
 
+def batch_norm_train(x, gamma, beta, eps=1e-5):
+    """Training-mode BatchNorm by explicit loops: per channel the mean and the biased variance over every (image,
+    row, column), then ((x - mean) / sqrt(var + eps)) * gamma + beta.  Returns (y, mean, var)."""
+    x = np.asarray(x, np.float64)
+    B, C, H, W = x.shape
+    y = np.zeros_like(x)
+    mean = np.zeros(C); var = np.zeros(C)
+    n = B * H * W
+    for c in range(C):
+        acc = 0.0
+        for b in range(B):
+            for i in range(H):
+                for j in range(W):
+                    acc += x[b, c, i, j]
+        mean[c] = acc / n
+        acc = 0.0
+        for b in range(B):
+            for i in range(H):
+                for j in range(W):
+                    acc += (x[b, c, i, j] - mean[c]) ** 2
+        var[c] = acc / n
+        y[:, c] = (x[:, c] - mean[c]) / np.sqrt(var[c] + eps) * float(gamma[c]) + float(beta[c])
+    return y, mean, var
+
+
+def philox4x32_10_scalar(ctr, key):
+    """One Philox-4x32-10 block with Python integers (Salmon et al. 2011): ctr 4 words, key 2 words -> 4 words."""
+    c0, c1, c2, c3 = (int(v) & 0xFFFFFFFF for v in ctr)
+    k0, k1 = (int(v) & 0xFFFFFFFF for v in key)
+    for _ in range(10):
+        p0 = c0 * 0xD2511F53
+        p1 = c2 * 0xCD9E8D57
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def dropout_keep(seed, b, c, y, x, C, W, keep_prob):
+    """Whether element (b, c, y, x) survives the build's dropout (see ldm_oracle.dropout_mask_nchw)."""
+    e = (y * W + x) * C + c
+    w = philox4x32_10_scalar((e // 4, 0xFFFFFFFE, b, 0x4C444D32), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))[e % 4]
+    u = np.float32(np.float32((w >> 8) + 0.5) * np.float32(2.0 ** -24))
+    return bool(u < np.float32(keep_prob))
+
+
 def silu(x):
     return x / (1.0 + np.exp(-x))
 

@@ -324,7 +324,7 @@ def test_diffusion_loss_value(A, O, dtype):
     ref = O.diffusion_loss(w, z, t.tolist(), T, n).item()
     _say(f"diffusion loss {dtype}")
     m = A.DiffusionModel(64, 3, T, 256, dtype=dtype, weights=w)
-    got = m.forward(z.cuda(), t.cuda(), n.cuda())
+    got = m.forward(z.cuda(), t.cuda(), n.cuda(), train=False)    # the sampler's semantics; training mode: test_gpu_train.py
     assert got.shape == (1,)
     e = abs(got.item() - ref) / abs(ref)
     _say(f"  loss={got.item():.6f} ref={ref:.6f} rel={e:.3e}")

@@ -228,3 +228,61 @@ def test_attention_query_chunks_do_not_change_the_result():
     for chunk in (7, 32, 119):
         part = O.attention(w, "m", x, q_chunk=chunk)
         assert (part - whole).abs().max().item() < 1e-5
+
+
+# ---- training-mode forward: batch-statistics BatchNorm and the dropout mask -------------------------
+def test_batch_norm_train_matches_loops_and_torch():
+    """burn's BatchNorm::forward_train: biased variance over (B, H, W); against explicit loops and against torch's own
+    training-mode batch_norm (a third statement of the same published definition)."""
+    x = _rand((3, 8, 5, 4), 31, 2.0) + 0.7
+    p = {"bn.gamma": _rand((8,), 32), "bn.beta": _rand((8,), 33)}
+    stats = {}
+    got = O.batch_norm_train(p, "bn", x, stats)
+    ref, mean, var = N.batch_norm_train(x.numpy(), p["bn.gamma"].numpy(), p["bn.beta"].numpy())
+    assert np.allclose(got.numpy(), ref, rtol=1e-10, atol=1e-10)
+    assert np.allclose(stats["bn"][0].numpy(), mean, rtol=1e-12) and np.allclose(stats["bn"][1].numpy(), var, rtol=1e-12)
+    tr = torch.nn.functional.batch_norm(x, None, None, p["bn.gamma"], p["bn.beta"], training=True, eps=O.BN_EPS)
+    assert torch.allclose(got, tr, rtol=1e-10, atol=1e-10)
+    # a batch of identical pixels has variance 0: the output is beta exactly
+    flat = torch.ones(2, 8, 3, 3, dtype=torch.float64) * 5.0
+    assert torch.allclose(O.batch_norm_train(p, "bn", flat), p["bn.beta"].reshape(1, 8, 1, 1).expand(2, 8, 3, 3))
+
+
+def test_dropout_mask_matches_the_scalar_generator():
+    B, C, H, W, seed = 2, 8, 3, 2, 0x1234567890ABCDEF
+    m = O.dropout_mask_nchw(seed, B, C, H, W, 0.5)
+    assert set(np.unique(m.numpy()).tolist()) <= {0.0, 1.0}
+    for b in range(B):
+        for c in range(C):
+            for y in range(H):
+                for x in range(W):
+                    assert bool(m[b, c, y, x]) == N.dropout_keep(seed, b, c, y, x, C, W, 0.5)
+    big = O.dropout_mask_nchw(7, 4, 64, 16, 16, 0.5)
+    assert abs(big.mean().item() - 0.5) < 0.01                       # Bernoulli(1/2) over 65 536 elements
+    assert abs(O.dropout_mask_nchw(7, 4, 64, 16, 16, 0.9).mean().item() - 0.9) < 0.01
+    assert not torch.equal(big, O.dropout_mask_nchw(8, 4, 64, 16, 16, 0.5))
+    x = torch.ones(4, 64, 16, 16)
+    d = O.dropout(x, 0.5, 7)
+    assert torch.equal(d, big * 2.0) and torch.equal(O.dropout(x, 0.0, 7), x)
+
+
+def test_training_forward_differs_from_inference_and_is_batch_coupled():
+    """Training semantics change the prediction (batch statistics, dropout) and couple the images of a batch."""
+    import diffusionmodel_amd as A
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 64, 8, 8, generator=g)
+    te = O.sin_time_addition(torch.tensor([1, 20, 300, 999]), 256)
+    with torch.no_grad():
+        inf = O.unet_forward(w, x, te)
+        stats = {}
+        tr = O.unet_forward(w, x, te, train=True, dropout_seed=5, stats=stats)
+        tr2 = O.unet_forward(w, x, te, train=True, dropout_seed=5)
+        nodrop = O.unet_forward(w, x, te, train=True, dropout_p=0.0)
+        half = O.unet_forward(w, x[:2], te[:2], train=True, dropout_p=0.0)
+    assert torch.equal(tr, tr2)
+    assert len(stats) == 14 and stats["down_res1.bn1"][0].shape == (64,) and stats["mid_res2.bn2"][1].shape == (256,)
+    assert (tr - inf).norm() / inf.norm() > 1e-2 and (tr - nodrop).norm() / nodrop.norm() > 1e-3
+    assert (half - nodrop[:2]).norm() / half.norm() > 1e-3          # the other images of the batch matter
+    loss = O.diffusion_loss(w, x, [1, 20, 300, 999], 1000, torch.randn(4, 64, 8, 8, generator=g), train=True, dropout_seed=5)
+    assert loss.shape == (1,) and torch.isfinite(loss).all()
