@@ -8,8 +8,9 @@
 // Three bandwidth-bound kernels on NHWC tensors (bf16 or f32, 16 bytes per lane):
 //   bn_partial_kernel   every workgroup reads a slice of pixels ONCE into registers and writes, per channel, the
 //                       slice's mean and its sum of squared deviations from THAT mean (no E[x^2] - mean^2);
-//   bn_finalize_kernel  merges the slices in a fixed order in f64 (Chan et al.'s pairwise update) into the batch
-//                       mean and variance: the result does not depend on scheduling;
+//   bn_finalize_kernel  merges the slices in f64 and in a fixed order into the batch mean and variance (the exact
+//                       decomposition M2 = sum of the slices' M2 + n (slice mean - mean)^2): the result does not
+//                       depend on scheduling;
 //   bn_apply_kernel     normalise + affine, then the ResidualBlock's tail in the same pass: SiLU and the block's time
 //                       vector (:375-382), or the residual add and SiLU (:386), optionally the dropout mask.
 #include "common.h"
@@ -26,6 +27,13 @@ template <> struct BnVec<float> {
         const f32x4 r = *(const f32x4*)p;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = r[e];
+    }
+    static __device__ __forceinline__ void unpack(const u32x4 r, float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int u = r[e];       // a copy: bit_cast applied to the element expression itself read element 0
+            v[e] = __builtin_bit_cast(float, u);
+        }
     }
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         f32x4 r;
@@ -44,6 +52,13 @@ template <> struct BnVec<bf16_t> {
             v[2 * e + 1] = bn_bf2f((bf16_t)(r[e] >> 16));
         }
     }
+    static __device__ __forceinline__ void unpack(const u32x4 r, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, r[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u);
+        }
+    }
     static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
         u32x4 r;
 #pragma unroll
@@ -52,126 +67,194 @@ template <> struct BnVec<bf16_t> {
     }
 };
 
-constexpr int BN_RMAX = 8;      // pixels a thread holds in registers
-constexpr int BN_SEGS = 16;     // segments of the slice list in the second stage
+constexpr int BN_RMAX = 16;     // pixels a thread holds in registers (as the 16 bytes it loaded)
+constexpr int BN_SEGS = 64;     // segments of the slice list in the second stage
+constexpr int BN_FCH = 4;       // channels per workgroup of the second stage
+
+// Sum of s[e] over the threads of a workgroup that share the channel lanes g (thread = r * G + g), left in every one
+// of them.  G a power of two up to 64: the rows inside a wave meet by butterfly exchanges (the same order in every
+// lane), the waves through LDS; other G (rows <= 256 / G): a loop over the rows in LDS.  red: 256 * VE floats.
+template <int VE>
+__device__ __forceinline__ void bn_rows_sum(float (&s)[VE], float* red, int tid, int G, int rows, int C, bool active,
+                                            bool pow2) {
+    const int r = tid / G, g = tid - r * G;
+    if (pow2) {
+        for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[e] += __shfl_xor(s[e], o, 64);
+        }
+        const int wave = tid >> 6, lane = tid & 63;
+        const int nw = (rows * G + 63) >> 6;
+        if (nw > 1) {
+            if (active && lane < G) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) red[wave * C + g * VE + e] = s[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float a = 0.f;
+                if (active)
+                    for (int w = 0; w < nw; ++w) a += red[w * C + g * VE + e];
+                s[e] = a;
+            }
+            __syncthreads();
+        }
+    } else {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) red[r * C + g * VE + e] = s[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float a = 0.f;
+            if (active)
+                for (int q = 0; q < rows; ++q) a += red[q * C + g * VE + e];
+            s[e] = a;
+        }
+        __syncthreads();
+    }
+}
 
 // h [P][C]; G = C / VE lanes per pixel, `rows` = pixels per pass (rows * G <= 256 threads are active), R <= BN_RMAX
 // passes: a workgroup owns rows * R consecutive pixels.  part [nblk][2][C] = {slice mean, slice M2}.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ h, long P, int C, int G, int rows, int R,
+// Every load is unconditional (a slot beyond the tensor reads the last pixel and is masked afterwards): a load under
+// a branch is followed by a wait before the next one is issued, which costs a memory latency per slot.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ h, long P, int C, int G, int rows,
                                                          float* __restrict__ part) {
     constexpr int VE = BnVec<T>::VE;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = (float*)smem_raw;                  // [rows][C]
+    float* red = (float*)smem_raw;                  // [rows or waves][C]
     const int tid = threadIdx.x;
     const bool active = tid < rows * G;
+    const bool pow2 = G <= 64 && (G & (G - 1)) == 0;
     const int r = tid / G, g = tid - r * G;
     const long base = (long)blockIdx.x * rows * R;
     long nblk = P - base;
     if (nblk > (long)rows * R) nblk = (long)rows * R;
-    float v[BN_RMAX][VE];
+    u32x4 raw[R];
     float s[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) s[e] = 0.f;
+    const int gl = active ? g : 0;
 #pragma unroll
-    for (int j = 0; j < BN_RMAX; ++j) {
-        const long p = base + (long)j * rows + r;
-        const bool ok = active && j < R && p < P;
-        if (ok) BnVec<T>::load(h + (size_t)p * C + g * VE, v[j]);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            if (!ok) v[j][e] = 0.f;
-            s[e] += v[j][e];
-        }
+    for (int j = 0; j < R; ++j) {
+        long p = base + (long)j * rows + r;
+        if (p > P - 1) p = P - 1;
+        raw[j] = *(const u32x4*)(h + (size_t)p * C + gl * VE);
     }
-    if (active) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) red[r * C + g * VE + e] = s[e];
+    for (int j = 0; j < R; ++j) {
+        const bool ok = active && base + (long)j * rows + r < P;
+        float v[VE];
+        BnVec<T>::unpack(raw[j], v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] += ok ? v[e] : 0.f;
     }
-    __syncthreads();
+    bn_rows_sum<VE>(s, red, tid, G, rows, C, active, pow2);
     float mean[VE];
     const float inv_n = 1.0f / (float)nblk;
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-        float a = 0.f;
-        if (active)
-            for (int q = 0; q < rows; ++q) a += red[q * C + g * VE + e];
-        mean[e] = a * inv_n;
+        mean[e] = s[e] * inv_n;
+        s[e] = 0.f;
     }
-    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < BN_RMAX; ++j) {
-        const long p = base + (long)j * rows + r;
-        const bool ok = active && j < R && p < P;
+    for (int j = 0; j < R; ++j) {
+        const bool ok = active && base + (long)j * rows + r < P;
+        float v[VE];
+        BnVec<T>::unpack(raw[j], v);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            const float d = ok ? v[j][e] - mean[e] : 0.f;
+            const float d = ok ? v[e] - mean[e] : 0.f;
             s[e] += d * d;
         }
     }
-    if (active) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) red[r * C + g * VE + e] = s[e];
-    }
-    __syncthreads();
+    bn_rows_sum<VE>(s, red, tid, G, rows, C, active, pow2);
     if (active && r == 0) {
         float* dst = part + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            float a = 0.f;
-            for (int q = 0; q < rows; ++q) a += red[q * C + g * VE + e];
             dst[g * VE + e] = mean[e];
-            dst[C + g * VE + e] = a;
+            dst[C + g * VE + e] = s[e];
         }
     }
 }
 
-// One workgroup per 16 channels: thread (segment, channel) merges its share of the slices one after the other, then
-// the 16 segment results are merged by the segment-0 thread, all in f64:
-//   n = na + nb;  d = mb - ma;  m = ma + d nb / n;  M2 = M2a + M2b + d^2 na nb / n.
+// Sum over the BN_SEGS segment values of one channel in a fixed order (a tree over LDS); every thread gets it.
+__device__ __forceinline__ double bn_seg_sum(double v, double (*sh)[BN_FCH], int seg, int cl) {
+    sh[seg][cl] = v;
+    __syncthreads();
+    for (int st = BN_SEGS / 2; st > 0; st >>= 1) {
+        if (seg < st) sh[seg][cl] += sh[seg + st][cl];
+        __syncthreads();
+    }
+    const double r = sh[0][cl];
+    __syncthreads();
+    return r;
+}
+
+// One workgroup per BN_FCH channels, thread (segment, channel): the slices' statistics merge exactly as
+//   mean = sum_b n_b mean_b / N,   M2 = sum_b [M2_b + n_b (mean_b - mean)^2],   var = M2 / N      (biased)
+// in f64, each sum over the thread's strided share of the slices and then over the segments in a fixed tree.
 // params [C][4] = {mean, sqrt(var + eps), gamma, beta}; mean_out / var_out [C] (optional): the batch statistics, for
 // the caller's running-average update (running = (1 - momentum) running + momentum batch, burn's momentum 0.1).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, long pix_per_blk, long P,
                                                           int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float* __restrict__ params, float* __restrict__ mean_out,
                                                           float* __restrict__ var_out) {
-    __shared__ double sm[BN_SEGS][16], sM2[BN_SEGS][16], sn[BN_SEGS][16];
-    const int cl = threadIdx.x & 15, seg = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    const int per = (nblk + BN_SEGS - 1) / BN_SEGS;
-    double n = 0.0, m = 0.0, M2 = 0.0;
-    if (c < C) {
-        const int b1 = min(nblk, (seg + 1) * per);
-        for (int b = seg * per; b < b1; ++b) {
-            long cnt = P - (long)b * pix_per_blk;
-            if (cnt > pix_per_blk) cnt = pix_per_blk;
-            const double nb = (double)cnt;
-            const double mb = (double)part[(size_t)b * 2 * C + c], M2b = (double)part[(size_t)b * 2 * C + C + c];
-            const double nn = n + nb, d = mb - m;
-            m += d * nb / nn;
-            M2 += M2b + d * d * n * nb / nn;
-            n = nn;
+    __shared__ double sh[BN_SEGS][BN_FCH];
+    const int cl = threadIdx.x % BN_FCH, seg = threadIdx.x / BN_FCH;
+    const int c = blockIdx.x * BN_FCH + cl;
+    const bool ok = c < C;
+    const int cc = ok ? c : C - 1;
+    const double N = (double)P;
+    const long last_cnt = P - (long)(nblk - 1) * pix_per_blk;
+    // the slices of a thread are visited eight at a time with all their loads issued first: a loop that waits for
+    // each load costs a memory latency per slice
+    double acc = 0.0;
+    for (int b0 = seg; b0 < nblk; b0 += 8 * BN_SEGS) {
+        float mb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * BN_SEGS;
+            mb[k] = part[(size_t)min(b, nblk - 1) * 2 * C + cc];     // unconditional: weighted by 0 below when unused
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * BN_SEGS;
+            const double nb = b >= nblk ? 0.0 : (double)(b == nblk - 1 ? last_cnt : pix_per_blk);
+            acc += nb * (double)mb[k];
         }
     }
-    sm[seg][cl] = m; sM2[seg][cl] = M2; sn[seg][cl] = n;
-    __syncthreads();
-    if (seg == 0 && c < C) {
-        for (int s2 = 1; s2 < BN_SEGS; ++s2) {
-            const double nb = sn[s2][cl];
-            if (nb == 0.0) continue;
-            const double nn = n + nb, d = sm[s2][cl] - m;
-            m += d * nb / nn;
-            M2 += sM2[s2][cl] + d * d * n * nb / nn;
-            n = nn;
+    const double mean = bn_seg_sum(acc, sh, seg, cl) / N;
+    acc = 0.0;
+    for (int b0 = seg; b0 < nblk; b0 += 8 * BN_SEGS) {
+        float mb[8], qb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * BN_SEGS;
+            mb[k] = part[(size_t)min(b, nblk - 1) * 2 * C + cc];
+            qb[k] = part[(size_t)min(b, nblk - 1) * 2 * C + C + cc];
         }
-        const float mean = (float)m, var = (float)(M2 / n);
-        params[c * 4 + 0] = mean;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * BN_SEGS;
+            const double nb = b >= nblk ? 0.0 : (double)(b == nblk - 1 ? last_cnt : pix_per_blk);
+            const double d = (double)mb[k] - mean;
+            acc += b >= nblk ? 0.0 : (double)qb[k] + nb * d * d;
+        }
+    }
+    const double M2 = bn_seg_sum(acc, sh, seg, cl);
+    if (ok && seg == 0) {
+        const float mf = (float)mean, var = (float)(M2 / N);
+        params[c * 4 + 0] = mf;
         params[c * 4 + 1] = sqrtf(var + eps);
         params[c * 4 + 2] = gamma[c];
         params[c * 4 + 3] = beta[c];
-        if (mean_out) mean_out[c] = mean;
+        if (mean_out) mean_out[c] = mf;
         if (var_out) var_out[c] = var;
     }
 }
@@ -217,15 +300,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
     constexpr int VE = BnVec<T>::VE;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f32x4* prm = (f32x4*)smem_raw;                  // [C]
-    for (int c = threadIdx.x; c < a.C; c += 256) prm[c] = *(const f32x4*)(a.params + c * 4);
-    __syncthreads();
+    float* tvl = (float*)(prm + a.C);               // [C]: the image's time vector
     const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        prm[c] = *(const f32x4*)(a.params + c * 4);
+        tvl[c] = a.tvec ? a.tvec[(size_t)b * a.t_img_stride + c] : 0.f;
+    }
+    __syncthreads();
     const int nvec = (int)(a.HW * a.G);
     const size_t img = (size_t)b * a.HW * a.C;
     const T* h = (const T*)a.h + img;
     const T* res = a.res ? (const T*)a.res + img : nullptr;
     T* out = (T*)a.out + img;
-    const float* tv = a.tvec ? a.tvec + (size_t)b * a.t_img_stride : nullptr;
+    const bool tv = a.tvec != nullptr;
     const bool drop = a.keep_prob < 1.0f;
     const float inv_keep = drop ? 1.0f / a.keep_prob : 1.0f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
@@ -251,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
             } else if (a.act == ACT_RELU) {
                 y = fmaxf(y, 0.f);
             }
-            if (tv) y += tv[c0 + e];
+            if (tv) y += tvl[c0 + e];
             v[e] = y;
         }
         if (drop) {
@@ -272,16 +359,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
 }
 
 // Launch geometry of the statistics stage for P pixels of C channels: lanes per pixel, pixels per pass, passes,
-// slices.  About 2048 slices when the tensor is large enough, never more than BN_RMAX pixels per thread.
+// slices.  Never more than BN_RMAX pixels per thread.
 int bn_plan(int dtype, long P, int C, BnPlan* pl) {
     const int ve = dtype == LDM_BF16 ? 8 : 4;
     LDM_REQUIRE(P > 0 && C > 0 && C % ve == 0 && C / ve <= 256, "channel count not served by the batch-statistics kernels");
     pl->G = C / ve;
     pl->rows = 256 / pl->G;
-    long R = (P + (long)pl->rows * 2048 - 1) / ((long)pl->rows * 2048);
-    if (R < 1) R = 1;
-    if (R > BN_RMAX) R = BN_RMAX;
-    pl->R = (int)R;
+    // about one slice per compute unit: with 1024 and more slices both stages took 2-3 times as long (a slice's
+    // life is a chain of memory latencies whatever its size, and the second stage reads every slice's record)
+    long R = (P + (long)pl->rows * 256 - 1) / ((long)pl->rows * 256);
+    int Rp = 1;                       // the kernel is instantiated for 1, 2, 4, 8 and 16 pixels per thread
+    while (Rp < R && Rp < BN_RMAX) Rp *= 2;
+    pl->R = Rp;
     pl->pix_per_blk = (long)pl->rows * pl->R;
     const long nblk = (P + pl->pix_per_blk - 1) / pl->pix_per_blk;
     LDM_REQUIRE(nblk <= 0x7fffffffL, "tensor too large for the batch-statistics kernels");
@@ -305,14 +394,21 @@ int launch_bn_stats(int dtype, const void* h, int B, long HW, int C, const float
     LDM_TRY(bn_plan(dtype, P, C, &pl));
     float* part = ws;
     float* params = ws + (size_t)pl.nblk * 2 * C;
-    const size_t lds = (size_t)pl.rows * C * 4;
-    if (dtype == LDM_BF16)
-        hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3((unsigned)pl.nblk), dim3(256), lds, s, (const bf16_t*)h, P, C, pl.G,
-                           pl.rows, pl.R, part);
-    else
-        hipLaunchKernelGGL(bn_partial_kernel<float>, dim3((unsigned)pl.nblk), dim3(256), lds, s, (const float*)h, P, C, pl.G,
-                           pl.rows, pl.R, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, (const float*)part, pl.nblk,
+    const size_t lds = (size_t)(pl.rows > 4 ? pl.rows : 4) * C * 4;
+    auto go = [&](auto kern_bf, auto kern_f) {
+        if (dtype == LDM_BF16)
+            hipLaunchKernelGGL(kern_bf, dim3((unsigned)pl.nblk), dim3(256), lds, s, (const bf16_t*)h, P, C, pl.G, pl.rows, part);
+        else
+            hipLaunchKernelGGL(kern_f, dim3((unsigned)pl.nblk), dim3(256), lds, s, (const float*)h, P, C, pl.G, pl.rows, part);
+    };
+    switch (pl.R) {
+        case 1: go(bn_partial_kernel<bf16_t, 1>, bn_partial_kernel<float, 1>); break;
+        case 2: go(bn_partial_kernel<bf16_t, 2>, bn_partial_kernel<float, 2>); break;
+        case 4: go(bn_partial_kernel<bf16_t, 4>, bn_partial_kernel<float, 4>); break;
+        case 8: go(bn_partial_kernel<bf16_t, 8>, bn_partial_kernel<float, 8>); break;
+        default: go(bn_partial_kernel<bf16_t, 16>, bn_partial_kernel<float, 16>); break;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + BN_FCH - 1) / BN_FCH)), dim3(256), 0, s, (const float*)part, pl.nblk,
                        pl.pix_per_blk, P, C, gamma, beta, eps, params, mean_out, var_out);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
@@ -339,7 +435,7 @@ int launch_bn_apply(int dtype, const void* h, const void* res, void* out, int B,
     const long want = (2048 + B - 1) / B;
     if (gx > want) gx = want;
     if (gx < 1) gx = 1;
-    const size_t lds = (size_t)C * 16;
+    const size_t lds = (size_t)C * 20;
     LDM_REQUIRE(lds <= 64 * 1024, "too many channels for the normalisation kernel");
     if (dtype == LDM_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)B), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((unsigned)gx, (unsigned)B), dim3(256), lds, s, a);
