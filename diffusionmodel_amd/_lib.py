@@ -46,6 +46,7 @@ SIGNATURES = {
     "ldm_add_noise": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _l, _vp]),
     "ldm_mse": (_i, [_vp, _vp, _l, _vp, _vp, _vp]),
     "ldm_mse_noalloc": (_i, [_vp, _vp, _l, _vp, _vp]),
+    "ldm_mse_noalloc_prepare": (_i, []),
     "ldm_latent_is_finite": (_i, [_vp, _l, _vp, _vp]),
     "ldm_last_kernel": (C.c_char_p, []),
     "ldm_vae_decoder_create": (_i, [C.POINTER(_vp), _i, _i, _i]),

@@ -184,6 +184,8 @@ int launch_add_noise(const float* x, const float* noise, const int* t, const flo
 int launch_mse(const float* a, const float* b, long n, float* partial_ws, float* out, hipStream_t s);
 // the same with the partial sums in an array of the code object (no workspace argument, no allocation)
 int launch_mse_noalloc(const float* a, const float* b, long n, float* out, hipStream_t s);
+// the per-device address of that array, resolved ahead of the first launch_mse_noalloc on the current device
+int mse_noalloc_prepare();
 // *flag = 1 if all n elements of z are finite, else 0 (two launches: a fill and the probe)
 int launch_finite_check(const float* z, long n, int* flag, hipStream_t s);
 // sinusoidal embedding of integer timesteps (src/main.rs:309-335)

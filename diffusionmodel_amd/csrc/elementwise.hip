@@ -188,17 +188,22 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
 // Finiteness probe of a latent (the checks of src/main.rs:780-784, 788-792 on the mean: a mean is NaN or infinite
 // as soon as one element is).  *flag is preset to 1 by a fill kernel; any wave that sees an element with an all-ones
 // exponent stores 0 (every writer stores the same value).
-__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ z, long n, int* __restrict__ flag) {
+// `head` elements in front of the first 16-byte boundary (a view that starts inside a larger tensor) and the tail
+// behind the last whole vector are read one by one.
+__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ z, long n, int head,
+                                                           int* __restrict__ flag) {
     bool bad = false;
-    const long n4 = n / 4;
-    const f32x4* z4 = (const f32x4*)z;
+    const long n4 = (n - head) / 4;
+    const f32x4* z4 = (const f32x4*)(z + head);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const f32x4 v = z4[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bad |= (__builtin_bit_cast(unsigned int, (float)v[q]) & 0x7f800000u) == 0x7f800000u;
     }
-    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    for (long i = head + n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         bad |= (__builtin_bit_cast(unsigned int, z[i]) & 0x7f800000u) == 0x7f800000u;
+    if (blockIdx.x == 0 && (int)threadIdx.x < head)
+        bad |= (__builtin_bit_cast(unsigned int, z[threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
     if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 0;
 }
 
@@ -714,6 +719,13 @@ static int mse_scratch(float** out) {
     return LDM_OK;
 }
 
+// Resolves the array's address on the current device (what the first allocation-free call on a device would do
+// itself): for callers that must not take the lock or load the code object inside the hot call, e.g. under capture.
+int mse_noalloc_prepare() {
+    float* ws = nullptr;
+    return mse_scratch(&ws);
+}
+
 int launch_mse_noalloc(const float* a, const float* b, long n, float* out, hipStream_t s) {
     LDM_REQUIRE(a && b && out && n > 0, "bad arguments");
     LDM_REQUIRE(n <= LDM_MSE_NOALLOC_MAX_N, "more elements than the allocation-free entry point takes (LDM_MSE_NOALLOC_MAX_N)");
@@ -725,9 +737,11 @@ int launch_mse_noalloc(const float* a, const float* b, long n, float* out, hipSt
 
 int launch_finite_check(const float* z, long n, int* flag, hipStream_t s) {
     LDM_REQUIRE(z && flag && n > 0, "bad arguments");
-    LDM_REQUIRE(((uintptr_t)z & 15) == 0, "the tensor must be 16-byte aligned");
+    LDM_REQUIRE(((uintptr_t)z & 3) == 0, "the tensor must be 4-byte aligned");
+    long head = (long)((16 - ((uintptr_t)z & 15)) & 15) / 4;     // elements before the first 16-byte boundary
+    if (head > n) head = n;
     LDM_TRY(launch_set_int(flag, 1, s));
-    hipLaunchKernelGGL(finite_check_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, z, n, flag);
+    hipLaunchKernelGGL(finite_check_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, z, n, (int)head, flag);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

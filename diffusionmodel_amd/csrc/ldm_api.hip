@@ -1114,19 +1114,36 @@ struct ldm_sampler {
     UnetBufs ub;
     float* z = nullptr;       // NHWC f32 state [B,H,W,clp]
     void* zl = nullptr;       // bf16 copy (bf16 mode)
-    float* coef = nullptr;    // [T][8]
-    int* d_ts = nullptr;      // [T]
+    // One plan per (mode, steps) a caller has asked for: its timestep and coefficient tables in device memory and
+    // the graphs captured over them (without / with injected noise).  A plan is built on first use and kept, so a
+    // caller that alternates samplers or step counts neither re-uploads nor re-captures anything.
+    struct Plan {
+        float* coef = nullptr;    // [steps][8]
+        int* d_ts = nullptr;      // [steps]
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
+    };
+    std::map<std::pair<int, int>, Plan> plans;
+    float* coef = nullptr;    // the tables of the plan of the current call
+    int* d_ts = nullptr;
     int* step = nullptr;      // device control words: {step counter, seed low, seed high, chain0, ticket}
     float* noise = nullptr;  // NHWC f32 [steps][B,H,W,clp], allocated on first use
     size_t noise_bytes = 0;
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int g_steps = -1, g_noise = -1, g_mode = -1;
-    std::vector<float> h_coef;
-    std::vector<int> h_ts;
-    int up_mode = -1, up_steps = -1;   // (mode, steps) whose tables are in device memory
+    void drop_graphs() {
+        for (auto& kv : plans)
+            for (hipGraphExec_t& e : kv.second.exec)
+                if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+    }
+    void drop_plans() {
+        drop_graphs();
+        for (auto& kv : plans) {
+            if (kv.second.coef) (void)hipFree(kv.second.coef);
+            if (kv.second.d_ts) (void)hipFree(kv.second.d_ts);
+        }
+        plans.clear();
+    }
     ~ldm_sampler() {
-        if (exec) (void)hipGraphExecDestroy(exec);
+        drop_plans();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (noise) (void)hipFree(noise);
     }
@@ -1233,6 +1250,8 @@ int ldm_mse(const float* a, const float* b, long n, float* ws1024, float* out, v
 int ldm_mse_noalloc(const float* a, const float* b, long n, float* out, void* stream) {
     return launch_mse_noalloc(a, b, n, out, (hipStream_t)stream);
 }
+
+int ldm_mse_noalloc_prepare(void) { return mse_noalloc_prepare(); }
 
 int ldm_latent_is_finite(const float* z, long n, int* flag, void* stream) {
     return launch_finite_check(z, n, flag, (hipStream_t)stream);
@@ -1551,8 +1570,6 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
         LDM_TRY(s->pool.alloc(&s->zl, nz * 2));
         LDM_HIP(hipMemset(s->zl, 0, nz * 2));
     }
-    LDM_TRY(s->pool.alloc((void**)&s->coef, (size_t)num_time * 8 * 4));
-    LDM_TRY(s->pool.alloc((void**)&s->d_ts, (size_t)num_time * 4));
     LDM_TRY(s->pool.alloc((void**)&s->step, 32));
     LDM_HIP(hipMemset(s->step, 0, 32));
     LDM_HIP(hipMemset(s->ub.tvec, 0, (size_t)num_time * tvt * 4));
@@ -1578,37 +1595,54 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
     hipStream_t st = (hipStream_t)stream;
     const int B = s->B, H = s->H, W = s->W, T = s->T;
     const int steps = mode == LDM_DDPM ? T : ddim_steps;
-    // The timestep and coefficient tables depend on (mode, steps) only: they are built and uploaded when those change
-    // (a synchronous copy, so the host vectors are free again when it returns), not on every call.
-    if (s->up_mode != mode || s->up_steps != steps) {
-        std::vector<float> c5;
+    LDM_REQUIRE(steps >= 1 && steps <= T, "the number of steps must be in [1, num_time]");
+    // The timestep and coefficient tables depend on (mode, steps) only.  A pair seen for the first time gets device
+    // tables of its own (a blocking copy into fresh memory that no earlier work reads: nothing has to be waited for);
+    // every later call with that pair finds them, and its graphs, in place.
+    auto key = std::make_pair(mode, steps);
+    auto pit = s->plans.find(key);
+    if (pit == s->plans.end()) {
+        if (s->plans.size() >= 32) {             // a caller cycling through many step counts: start over
+            LDM_HIP(hipDeviceSynchronize());
+            s->drop_plans();
+        }
+        std::vector<float> c5, h_coef;
+        std::vector<int> h_ts;
         if (mode == LDM_DDPM) {
             host_ddpm_coef(T, c5);
-            s->h_ts.resize(T);
-            s->h_coef.assign((size_t)T * 8, 0.f);
+            h_ts.resize(T);
+            h_coef.assign((size_t)T * 8, 0.f);
             for (int k = 0; k < T; ++k) {
                 const int i = T - 1 - k;
-                s->h_ts[k] = i;
-                for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)i * 5 + q];
-                s->h_coef[(size_t)k * 8 + 5] = 0.f;
-                s->h_coef[(size_t)k * 8 + 6] = i == 0 ? 1.f : 0.f;
+                h_ts[k] = i;
+                for (int q = 0; q < 5; ++q) h_coef[(size_t)k * 8 + q] = c5[(size_t)i * 5 + q];
+                h_coef[(size_t)k * 8 + 5] = 0.f;
+                h_coef[(size_t)k * 8 + 6] = i == 0 ? 1.f : 0.f;
             }
         } else {
-            LDM_TRY(host_ddim_ts(T, steps, s->h_ts));
+            LDM_TRY(host_ddim_ts(T, steps, h_ts));
             LDM_TRY(host_ddim_coef(T, steps, c5));
-            s->h_coef.assign((size_t)steps * 8, 0.f);
+            h_coef.assign((size_t)steps * 8, 0.f);
             for (int k = 0; k < steps; ++k) {
-                for (int q = 0; q < 5; ++q) s->h_coef[(size_t)k * 8 + q] = c5[(size_t)k * 5 + q];
-                s->h_coef[(size_t)k * 8 + 5] = 1.f;
+                for (int q = 0; q < 5; ++q) h_coef[(size_t)k * 8 + q] = c5[(size_t)k * 5 + q];
+                h_coef[(size_t)k * 8 + 5] = 1.f;
             }
         }
-        s->up_mode = s->up_steps = -1;
-        // work of earlier calls may still read the old tables
-        LDM_HIP(hipDeviceSynchronize());
-        LDM_HIP(hipMemcpy(s->d_ts, s->h_ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice));
-        LDM_HIP(hipMemcpy(s->coef, s->h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice));
-        s->up_mode = mode; s->up_steps = steps;
+        ldm_sampler::Plan pl;
+        LDM_HIP(hipMalloc((void**)&pl.coef, (size_t)steps * 8 * 4));
+        hipError_t e = hipMalloc((void**)&pl.d_ts, (size_t)steps * 4);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_ts, h_ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl.coef, h_coef.data(), (size_t)steps * 8 * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(pl.coef);
+            if (pl.d_ts) (void)hipFree(pl.d_ts);
+            LDM_HIP(e);
+        }
+        pit = s->plans.emplace(key, pl).first;
     }
+    ldm_sampler::Plan& plan = pit->second;
+    s->coef = plan.coef;
+    s->d_ts = plan.d_ts;
     const bool have_noise = noise_dev != nullptr && mode == LDM_DDPM;
     const size_t nz = (size_t)B * H * W * m->clp;
     if (have_noise) {
@@ -1619,7 +1653,7 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
             s->noise = nullptr; s->noise_bytes = 0;
             LDM_HIP(hipMalloc((void**)&s->noise, need));
             s->noise_bytes = need;
-            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+            s->drop_graphs();                     // they hold the old buffer's address
         }
     }
     // time path for every visited timestep at once: [steps, tv_total] table (all chains share t)
@@ -1644,8 +1678,8 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
     LDM_TRY(launch_set_ctl(s->step, seed, chain0, st));
     const bool tracing = z_trace || eps_trace;
     if (use_graph && !tracing) {
-        if (!s->exec || s->g_steps != steps || s->g_noise != (int)have_noise || s->g_mode != mode) {
-            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+        hipGraphExec_t& exec = plan.exec[have_noise ? 1 : 0];
+        if (!exec) {
             hipGraph_t graph = nullptr;
             LDM_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = LDM_OK;
@@ -1654,12 +1688,12 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
             hipError_t e = hipStreamEndCapture(s->cap_stream, &graph);
             if (rc != LDM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LDM_HIP(e);
-            e = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) exec = nullptr;
             LDM_HIP(e);
-            s->g_steps = steps; s->g_noise = (int)have_noise; s->g_mode = mode;
         }
-        LDM_HIP(hipGraphLaunch(s->exec, st));
+        LDM_HIP(hipGraphLaunch(exec, st));
     } else {
         for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, mode, have_noise, seed, chain0, z_trace, eps_trace, k, st));
     }

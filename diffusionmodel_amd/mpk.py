@@ -260,7 +260,9 @@ def save_model_weights(path: str, unet: Dict[str, np.ndarray], decoder: Optional
                 _insert(item, k, None)
     meta = {"float": {"F16": "f16", "BF16": "bf16", "F32": "f32", "F64": "f64"}[dtype], "int": "i16",
             "format": "burn_core::record::file::NamedMpkFileRecorder", "version": BURN_VERSION,
-            "settings": "HalfPrecisionSettings" if dtype == "F16" else "custom"}
+            # burn writes core::any::type_name of the settings type here (a full path) and only ever reads it back
+            # for the text of a mismatch error
+            "settings": "burn_core::record::settings::HalfPrecisionSettings" if dtype == "F16" else "custom"}
     tmp = path + ".tmp"
     with open(tmp, "wb") as fh:
         fh.write(msgpack.packb({"metadata": meta, "item": item}, use_bin_type=True))

@@ -166,9 +166,13 @@ int ldm_mse(const float* a_dev, const float* b_dev, long n, float* ws1024_dev, f
  * harnesses that forbid hipMalloc): no counterpart in the reference.  The 1024 partial sums live in a 4-KiB array
  * inside the library's code object (one copy per GPU, held until the process ends) instead of a workspace argument;
  * the call allocates nothing and returns the same value as ldm_mse, bit for bit.  n above LDM_MSE_NOALLOC_MAX_N is
- * rejected.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race. */
+ * rejected.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race.
+ * The first call on a GPU looks the array's address up (hipGetSymbolAddress under a lock, which may load the code
+ * object): a caller that captures its calls into a graph makes that first call, or calls ldm_mse_noalloc_prepare
+ * with the GPU current, BEFORE the capture begins; after that the call only launches the two kernels. */
 #define LDM_MSE_NOALLOC_MAX_N (1L << 36)
 int ldm_mse_noalloc(const float* a_dev, const float* b_dev, long n, float* out_dev, void* stream);
+int ldm_mse_noalloc_prepare(void);
 
 /* ---- one convolution on NHWC tensors in the library's own layout (kernel-level operator) --- */
 /* The burn layers behind it: Conv2d 3x3 stride 1 / stride 2 padding 1 (src/main.rs:348-366,423-452,
@@ -201,8 +205,9 @@ int ldm_sched_step(float* z_dev, const float* eps_dev, const float* noise_dev, l
 /* The loop runs on `batch` independent chains of shape [in_channels,H,W]; the trailing vae.decode
  * (:786) is outside this library.  ldm_sampler_create allocates the activation buffers, the state and the tables;
  * ldm_sampler_run allocates only when the caller injects per-step noise (noise_dev): a buffer for its NHWC copy,
- * on first use and when more steps are asked for (that synchronises the device).  The timestep and coefficient
- * tables are uploaded when (mode, steps) change, not per call.
+ * on first use and when more steps are asked for (that synchronises the device).  A (mode, steps) pair seen for the
+ * first time gets timestep and coefficient tables of its own (one blocking upload into fresh memory) and, with
+ * use_graph, its own captured graph; both are kept, so alternating samplers or step counts costs nothing later.
  * At H = W = 4, the latent size of the reference's VAE, the sampler (and ldm_unet_forward) runs every
  * spatial layer as one matrix between whole images, built at ldm_module_finalize (LDM_DENSE4 above). */
 int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int batch, int H, int W);
@@ -224,7 +229,7 @@ void ldm_sampler_destroy(ldm_sampler* s);
  * (:647-651, 657-662, 672-676).  The reference reads the mean back and tests it; a mean is NaN or infinite as soon as
  * one element is, so this probe looks at the elements: *flag_dev = 1 when all n f32 elements of z_dev are finite,
  * 0 otherwise.  Two small launches on `stream`, no host synchronisation: the caller reads the flag when it wants
- * to and applies the reference's fallback (zeros, or the loss value 100).  z_dev must be 16-byte aligned. */
+ * to and applies the reference's fallback (zeros, or the loss value 100).  z_dev may be any f32 view (4-byte aligned). */
 int ldm_latent_is_finite(const float* z_dev, long n, int* flag_dev, void* stream);
 
 /* Standard-normal field of the counter-based generator, [batch,C,H,W] f32 (C multiple of 4):

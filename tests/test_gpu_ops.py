@@ -469,19 +469,40 @@ def test_unet_scaled_larger_latents(A, O, dtype, B, S):
     assert e < TOL[dtype]
 
 
-def test_unet_scaled_full_size_properties(A):
-    """Scaled UNet at 256x256 latents, bf16, four images (16 384- and 4 096-token attention on the long-sequence
-    kernels): finite; the whole batch equals its two halves (which take other attention kernels: another summation
-    order, nothing else); a DDIM loop replayed from its graph equals the eager loop bit for bit, twice."""
+def test_unet_scaled_at_the_config4_latent_size_against_the_oracle(A, O):
+    """BASELINE config 4's network at its own latent size: the scaled UNet on [1,64,256,256], bf16, against the CPU
+    restatement (16 384- and 4 096-token attention; the restatement builds its score matrices 2 048 query rows at a
+    time)."""
+    cfg = A.LDMConfig.scaled()
+    w = A.make_synthetic_weights(cfg, 0)
+    x = torch.randn(1, 64, 256, 256, generator=torch.Generator().manual_seed(2560))
+    te = O.sin_time_addition(torch.tensor([640]), 256)
+    _say("unet scaled 256x256 bf16 vs oracle")
+    with torch.no_grad():
+        ref = O.unet_forward(w, x, te, scaled_attention=True)
+    net = A.UNet(64, 256, channels=cfg.channels, scaled_attention=True, dtype="bf16", weights=w)
+    got = net(x.cuda(), te.cuda())
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    _say(f"  rel_err={e:.3e}")
+    assert torch.isfinite(got).all() and e < TOL["bf16"]
+
+
+@pytest.mark.parametrize("B", [4, 16])
+def test_unet_scaled_full_size_properties(A, B):
+    """Scaled UNet at 256x256 latents, bf16, four images and sixteen (the share of one GPU in the 8-GPU run of config
+    4; 16 384- and 4 096-token attention on the long-sequence kernels): finite; the whole batch equals its two halves
+    (which take other attention kernels: another summation order, nothing else); a DDIM loop replayed from its graph
+    equals the eager loop bit for bit, twice."""
     cfg = A.LDMConfig.scaled()
     w = A.make_synthetic_weights(cfg, 0)
     g = torch.Generator().manual_seed(256)
-    x = torch.randn(4, 64, 256, 256, generator=g).cuda()
-    te = A.sin_time_addition(torch.tensor([999, 500, 20, 0]).cuda(), 256)
-    _say("unet scaled 256x256 bf16: batch slices")
+    x = torch.randn(B, 64, 256, 256, generator=g).cuda()
+    te = A.sin_time_addition(torch.tensor(([999, 500, 20, 0] * 4)[:B]).cuda(), 256)
+    _say(f"unet scaled 256x256 bf16, {B} images: batch slices")
     net = A.UNet(64, 256, channels=cfg.channels, scaled_attention=True, dtype="bf16", weights=w)
     whole = net(x, te)
-    parts = torch.cat([net(x[i:i + 2].contiguous(), te[i:i + 2].contiguous()) for i in (0, 2)])
+    parts = torch.cat([net(x[i:i + B // 2].contiguous(), te[i:i + B // 2].contiguous()) for i in (0, B // 2)])
     torch.cuda.synchronize()
     e = rel_err(whole, parts)
     _say(f"  whole batch vs halves: rel_err={e:.3e}")
@@ -490,11 +511,11 @@ def test_unet_scaled_full_size_properties(A):
     del net
     _say("unet scaled 256x256 bf16: graph vs eager")
     m = A.DiffusionModel(64, 3, 1000, 256, cfg.channels, True, dtype="bf16", weights=w)
-    eager = m.ddim_sample(4, 3, spatial=256, z0=x, use_graph=False)
+    eager = m.ddim_sample(B, 3, spatial=256, z0=x, use_graph=False)
     torch.cuda.synchronize()
     assert torch.isfinite(eager).all()
     for _ in range(2):
-        zg = m.ddim_sample(4, 3, spatial=256, z0=x, use_graph=True)
+        zg = m.ddim_sample(B, 3, spatial=256, z0=x, use_graph=True)
         torch.cuda.synchronize()
         assert torch.equal(zg, eager)
 

@@ -42,3 +42,40 @@ def test_mse_noalloc_matches_mse_on_two_calls_in_a_row():
     rc = lib.ldm_mse_noalloc(C.c_void_p(a.data_ptr()), C.c_void_p(a.data_ptr()), (1 << 36) + 1, C.c_void_p(out.data_ptr()),
                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 1 and b"LDM_MSE_NOALLOC_MAX_N" in lib.ldm_last_error()
+
+
+def test_mse_noalloc_allocates_nothing_and_replays_from_a_graph():
+    """With the output preallocated, device memory in use is the same before and after the call; after the set-up
+    call (ldm_mse_noalloc_prepare) the entry point can be captured into a graph, and every replay -- with the
+    program's own eager work and synchronisations in between -- gives the bits of the eager call."""
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.ldm_mse_noalloc_prepare())
+    g = torch.Generator().manual_seed(13)
+    n = 64 * 64 * 64 + 5
+    a = torch.randn(n, generator=g).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    out = torch.full((1,), -1.0, dtype=torch.float32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    alloc0 = torch.cuda.memory_allocated()
+    _lib.check(lib.ldm_mse_noalloc(p(a), p(b), n, p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0 and torch.cuda.memory_allocated() == alloc0
+    eager = out.clone()
+    assert torch.equal(eager, _mse(lib, False, a, b))
+    st = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    out.fill_(-1.0)
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gr, stream=st):
+            _lib.check(lib.ldm_mse_noalloc(p(a), p(b), n, p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for k in range(3):
+        out.fill_(-1.0)
+        other = _mse(lib, False, b, a * float(k + 2))          # eager work of the program between the replays
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager), (k, out.item(), eager.item())
+        assert other.item() > 0
