@@ -135,6 +135,13 @@ bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, in
 int launch_upfuse(const PackedConv& pc, const void* x, const void* skip, void* out, int B, int Hin, int Win,
                   hipStream_t stream);
 
+// Fused ResidualBlock (conv3x3 + SiLU + time vector, conv3x3 + residual + SiLU; src/main.rs:372-387) of the 64-channel
+// level: x and out [B,H,64,64] bf16 NHWC, c1 / c2 the block's packed convolutions (BatchNorm folded in),
+// tvec[img * t_img_stride + step * t_step_stride + c] the block's time vector.
+bool resfuse_shape_ok(int dtype, int C, int B, int H, int W);
+int launch_resfuse(const PackedConv& c1, const PackedConv& c2, const void* x, void* out, int B, int H, int W,
+                   const float* tvec, int t_img_stride, int t_step_stride, const int* step_ptr, hipStream_t stream);
+
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
 // Name of the kernel the calling thread's last launch_tapconv / launch_upfuse started, spelled as a profiler lists it

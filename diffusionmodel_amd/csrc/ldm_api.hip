@@ -863,6 +863,10 @@ static int run_conv(const PackedConv& pc, const void* in0, int cin0, const void*
 // ResidualBlock::forward (src/main.rs:372-387): tmp = silu(bn1(conv1(x))) + t ; out = silu(bn2(conv2(tmp)) + x)
 static int run_resblock(const ResBlockP& rp, const void* x, void* tmp, void* out, int B, int H, int W, const TimeVec& tv,
                         hipStream_t st) {
+    // LDM_RESFUSE=0 (developer switch, read once): keep the two launches where the fused kernel would run
+    static const bool fuse = [] { const char* e = getenv("LDM_RESFUSE"); return !(e && e[0] == '0'); }();
+    if (fuse && tv.pix_stride == 0 && resfuse_shape_ok(rp.c1.dtype, rp.C, B, H, W))
+        return launch_resfuse(rp.c1, rp.c2, x, out, B, H, W, tv.table + rp.tv_off, tv.img_stride, tv.step_stride, tv.step_ptr, st);
     LDM_TRY(run_conv(rp.c1, x, rp.C, nullptr, 0, tmp, B, H, W, ACT_SILU, nullptr, &tv, rp.tv_off, 0, st));
     LDM_TRY(run_conv(rp.c2, tmp, rp.C, nullptr, 0, out, B, H, W, ACT_SILU, x, nullptr, 0, 0, st));
     return LDM_OK;

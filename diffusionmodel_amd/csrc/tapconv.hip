@@ -52,6 +52,16 @@
 #ifndef TAPCONV_NO_WS64
 #define TAPCONV_NO_WS64 0
 #endif
+// the same for the 64-channel weight-stationary kernel: 1 no window DMA after the first tile, 2 no output stores,
+// 4 no staging of the epilogue's inputs (wrong results: timing only)
+#ifndef WS64_ABLATE
+#define WS64_ABLATE 0
+#endif
+// epilogue inputs of the 64-channel weight-stationary kernel (residual rows, rows of the sampler state, time vector):
+// 1 = loaded straight into registers by asm loads with counted waits, 0 = staged through LDS by LDS-DMA
+#ifndef WS64_REGLOAD
+#define WS64_REGLOAD 0
+#endif
 #ifndef TAPCONV_WS_XD
 #define TAPCONV_WS_XD 4
 #endif
@@ -154,6 +164,8 @@ struct TapConvArgs {
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
+    const char* w2;              // fused ResidualBlock: packed weights and bias of the second convolution
+    const float* bias2;
     int early_num;               // persistent kernels with two workgroups per CU: eighths of a pair's tiles for its first workgroup (0: even split)
     unsigned magic_tpi, magic_tx; // stride-2 persistent kernel: ceil(2^32 / tiles per image), ceil(2^32 / tiles_x) (see fast_div)
 #ifdef TAPCONV_STAMP
@@ -866,7 +878,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         hix0 = (trem % a.tiles_x) * 16 - 1;
         hbase = a.in0 + (size_t)img * a.Hin * a.Win * 128 + (lane & 1) * 16 + wave * 32;
     };
+    bool in_loop = false;
     auto halo_piece = [&](int q, int buf) {
+        if ((WS64_ABLATE & 1) && in_loop) return;
         const int iy = hiy0 + (hyx[q] >> 8), ix = hix0 + (hyx[q] & 255);
         const bool ok = hlive && hyx[q] >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         const char* src = ok ? hbase + (size_t)(iy * a.Win + ix) * 128 : zero;
@@ -875,6 +889,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     halo_origin(tile);
 #pragma unroll
     for (int q = 0; q < NG; ++q) halo_piece(q, 0);
+    in_loop = true;
 
     // epilogue constants: after the lane swap this lane owns channels co .. co+7 of pixel column l15
     const unsigned hlane = (g >> 1) * HPLANE + ((wm * 2 * HR) * HW + l15) * 32 + (g & 1) * 16;
@@ -896,6 +911,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     // needs, the time vector and the element offset of their first row
     f32x4 accP[NF][HR];
     u32x4 ldP[NLDG > 1 ? NLDG : 2];
+    // WS64_REGLOAD: the loads issued during a first half land in ldA, those of a second half in ldB; the epilogue
+    // of a half runs during the next one and reads the other set
+    u32x4 ldA[NLDG > 1 ? NLDG : 2], ldB[NLDG > 1 ? NLDG : 2];
     size_t eP = 0;
     char* stage = smem + 2 * HALO_BYTES + wave * (NLDG * 1024);      // wave-uniform: DMA destination base
     f32x4 v0, v1;          // the row that is passing through the epilogue slices
@@ -965,6 +983,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             o[1] = pack2(v0[2], v0[3]);
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
+            if ((WS64_ABLATE & 2) && o[0] != 0x12345678u) return;
 #if TAPCONV_DDIM_O_PLAIN
             if constexpr (DDIM) *(u32x4*)(a.out + eo * 2) = o;
             else store_out(a.out + eo * 2, o);
@@ -995,9 +1014,22 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
         e0 = (((size_t)img * a.Hout + y0 + wm * 2 * HR) * a.Wout + x0 + l15) * 64 + co;
     };
-    auto read_staged = [&]() {
+    // the epilogue inputs of the half that just ended become ldP; second_half: this half is a second half (the
+    // finished one was a first half).  Called after the counted wait that covers them.
+    auto read_staged = [&](bool second_half) {
+#if WS64_REGLOAD
+        // the registers were written by loads the compiler does not see: every later use hangs on this statement,
+        // which stands behind the wait
+#pragma unroll
+        for (int i = 0; i < NLDG; ++i) {
+            if (second_half) { asm volatile("" : "+v"(ldA[i])); ldP[i] = ldA[i]; }
+            else { asm volatile("" : "+v"(ldB[i])); ldP[i] = ldB[i]; }
+        }
+#else
+        (void)second_half;
 #pragma unroll
         for (int i = 0; i < NLDG; ++i) ldP[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+#endif
     };
 
     // half_tag: second half of the tile; epi_tag: a previous half exists (its epilogue runs here);
@@ -1010,7 +1042,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         if (EPI && NLDG > 0) {
             if (WAIT == 1) wait_vmcnt<2 * NST>();
             if (WAIT == 2) wait_vmcnt<0>();
-            read_staged();
+            read_staged(HALF == 1);
         }
         const size_t eC = e0 + HALF * HR * erow;
         f32x4 acc[NF][HR];
@@ -1041,7 +1073,14 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
                 if (RES) src = a.res + (eC + i * erow) * 2;
                 else if (DDIM) src = (const char*)(a.sched_z + eC + (i >> 1) * erow + (i & 1) * 4);
                 else src = (const char*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co + i * 4);
-                glds16(src, stage + i * 1024);
+#if WS64_REGLOAD
+                if (!(WS64_ABLATE & 4)) {
+                    if (HALF) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldB[i]) : "v"(src) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldA[i]) : "v"(src) : "memory");
+                }
+#else
+                if (!(WS64_ABLATE & 4)) glds16(src, stage + i * 1024);
+#endif
             }
             // 18 epilogue slices over the 24 fragment steps (the stores fall on steps 10 and 22)
             if (EPI && f % 4 != 3) epi_slice(slice);
@@ -1089,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     }
     // the last half's epilogue
     wait_vmcnt<0>();
-    read_staged();
+    read_staged(false);             // the last half was a second half: its inputs are in the other set
 #pragma unroll
     for (int s = 0; s < KS; ++s) epi_slice(s);
     WS_STAMP_END();
@@ -1107,6 +1146,332 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused ResidualBlock of the 64-channel level on 64-pixel-wide images (bf16, running statistics folded in):
+//   y = silu(conv1(x) + b1) + t ;  out = silu(conv2(y) + b2 + x)                        (src/main.rs:372-387)
+// as ONE kernel: y never goes to memory and x is read once (plus once, from L2, as the residual).
+//
+// A workgroup owns a band of RF_R = 16 output rows of one image over the whole width and walks down it two rows per
+// step.  Full-width rows make every 16-pixel MFMA fragment a piece of ONE image row, so conv1 is recomputed only on
+// the two rim rows above and below the band (18 rows of y for 16 rows of output).  Eight waves: waves 0-3 compute
+// conv1 ("producers"), waves 4-7 conv2 ("consumers"); a wave owns 32 pixel columns x 32 output channels and keeps its
+// convolution's 144 weight registers for the whole kernel, as in the kernel above; every SIMD hosts one wave of each.
+//   x rows enter an 8-row LDS ring by LDS-DMA, a pair of rows per step, issued two steps ahead;
+//   producers at step k write the y rows 2k-1 and 2k (band relative) as bf16 into a second 8-row LDS ring;
+//   consumers run three steps behind and read the four y rows their two output rows need from that ring.
+// Ring rows hold the 64 pixels of an image row in the pair-plane layout (no border columns): a lane whose pixel lies
+// left or right of the image reads a zero pixel kept behind the ring instead (one select per affected read).  Rows
+// above or below the image are zeros: the x ring gets them from the zero page, the y ring from the producers.
+// One barrier per step; per half (16 columns) a wave runs the 72 MFMAs of two output rows with the previous half's
+// epilogue and its share of the memory operations spread between them, exactly as the kernel above does.
+// ---------------------------------------------------------------------------------------------
+constexpr int RF_R = 16;                                // output rows per workgroup
+constexpr int RF_RING = 8;                              // rows of each ring
+constexpr int RF_ROWB = 64 * 32;                        // bytes of a ring row in one pair plane
+constexpr int RF_PLANE = (RF_RING * 64 + 1) * 32;       // a pair plane: the ring rows, then the zero pixel
+constexpr int RF_RINGB = 4 * RF_PLANE;
+constexpr int RF_NPROD = RF_R / 2 + 1;                  // producer steps (18 rows of y)
+constexpr int RF_LAG = 3;                               // consumers run this many steps behind
+constexpr int RF_NS = RF_R / 2 + RF_LAG;                // steps of a workgroup
+constexpr int RF_LDS = 2 * RF_RINGB + 8 * 1024 + 8 * 1024;   // two rings, a 1-KiB dump area per wave, 2 KiB of residual staging per consumer wave
+
+__global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) {
+    constexpr int NF = 2, KS = 18, HR = 2, XD = 3;
+#ifdef TAPCONV_STAMP
+    // diagnostic builds: 100-MHz real-time stamps of wave 0 (producer) and wave 4 (consumer), 16 slots each: start,
+    // prologue done, end of every step, end (tools/rflife.py prints them)
+#define RF_STAMP(k_) do { if (a.dbg_rt && (threadIdx.x & 255) == 0) a.dbg_rt[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 16 + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RF_STAMP(k_) do { } while (0)
+#endif
+    RF_STAMP(0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave >= 4;
+    const int wn = wave & 1, wf = (wave >> 1) & 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const char* zero = (const char*)g_zero16;
+    const int bands = a.Hin / RF_R;
+    const int img = blockIdx.x / bands, y0 = (blockIdx.x % bands) * RF_R;
+    char* const xring = smem;
+    char* const yring = smem + RF_RINGB;
+    char* const dump = smem + 2 * RF_RINGB + wave * 1024;
+    // consumers: the residual rows of the half whose epilogue is pending, 1 KiB per row (16 bytes per lane)
+    char* const stage = smem + 2 * RF_RINGB + 8 * 1024 + (wave & 3) * 2048;
+
+    // the zero pixel of both rings (read by lanes whose pixel lies beside the image)
+    if (tid < 16) {
+        const int ring = tid >> 3, plane = (tid >> 1) & 3, sub = tid & 1;
+        *(u32x4*)(smem + ring * RF_RINGB + plane * RF_PLANE + RF_RING * RF_ROWB + sub * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // this wave's 32 output channels of every (tap, half) of ITS convolution
+    const char* wsrc = consumer ? a.w2 : a.w;
+    u32x4 wreg[KS][NF];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            wreg[ks][nf] = *(const u32x4*)(wsrc + (ks >> 1) * 8192 + ((ks & 1) * 2 + (g >> 1)) * 2048 +
+                                           ((wn * NF + nf) * 16 + l15) * 32 + (g & 1) * 16);
+
+    // after the lane swap of the epilogue this lane owns channels co .. co+7 of pixel column l15
+    const int co = wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
+    const float* bsrc = consumer ? a.bias2 : a.bias;
+    const f32x4 b0 = *(const f32x4*)(bsrc + co), b1 = *(const f32x4*)(bsrc + co + 4);
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    // ld: the residual rows of the half whose epilogue is pending (consumers), or the block's time vector of this
+    // lane's eight channels (producers)
+    u32x4 ld[HR] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if (!consumer) {
+        const float* tp = a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co;
+        ld[0] = *(const u32x4*)tp;
+        ld[1] = *(const u32x4*)(tp + 4);
+    }
+    // the loads above are ordinary loads: they are complete before the first LDS-DMA piece is issued, so the counted
+    // waits below only ever see the pieces, the residual loads and the stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // x rows: pair q holds the band-relative rows 2q-2 and 2q-1 in the ring rows (2q & 7) and (2q & 7) + 1.  Its 16
+    // pieces (4 planes x 2 rows x 2 halves of a row) are issued by the 8 waves, two each: piece e = wave * 2 + i.
+    const size_t img_base = (size_t)img * a.Hin * 64;
+    auto issue_piece = [&](int q, int i, bool live) {
+        const int e = wave * 2 + i;
+        const int plane = e >> 2, rr = (e >> 1) & 1, hx = (e & 1) * 32 + (lane >> 1);
+        const int iy = y0 + 2 * q - 2 + rr;
+        const bool ok = live && (unsigned)iy < (unsigned)a.Hin;
+        const char* src = ok ? a.in0 + (img_base + (size_t)iy * 64 + hx) * 128 + plane * 32 + (lane & 1) * 16 : zero;
+        char* dst = live ? xring + plane * RF_PLANE + (((2 * q) & 7) + rr) * RF_ROWB + (e & 1) * 1024 : dump;
+        glds16(src, dst);
+    };
+    constexpr int QMAX = RF_NPROD;                          // the last producer step needs the pairs QMAX-1 and QMAX
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        issue_piece(q, 0, true);
+        issue_piece(q, 1, true);
+    }
+
+    // per-lane pieces of the fragment addresses: plane and half of the lane, pixel offsets of the three column shifts
+    const unsigned lane_po = (g >> 1) * RF_PLANE + (g & 1) * 16;
+    const unsigned zpix = RF_RING * RF_ROWB + lane_po;     // the zero pixel, in this lane's plane
+    // output addressing: element offset of (row 0 of the band, column l15, channel co)
+    const size_t out_base = (img_base + (size_t)y0 * 64 + l15) * 64 + co;
+
+    f32x4 accP[NF][HR];
+    int rowP = 0, colP = 0;        // first row (band relative) and first column of the half whose epilogue is pending
+    f32x4 v0, v1;
+
+    // Slice s (0..17) of the pending half's epilogue: row s/9; step 0 swaps lanes and adds bias (and residual), steps
+    // 1..7 apply SiLU, step 8 finishes and writes: producers to the y ring, consumers to memory.
+    auto epi_slice = [&](auto role_tag, int s18) {
+        constexpr bool CONS = decltype(role_tag)::value;
+        const int j = s18 / 9, s = s18 % 9;
+        if (s == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accP[0][j][q]), f2u(accP[1][j][q]), false, false);
+                v0[q] = u2f(sw[0]);
+                v1[q] = u2f(sw[1]);
+            }
+            v0 += b0;
+            v1 += b1;
+            if (CONS) {
+                const unsigned int u0 = ld[j][0], u1 = ld[j][1], u2 = ld[j][2], u3 = ld[j][3];
+                v0[0] += bf2f((bf16_t)(u0 & 0xffffu)); v0[1] += bf2f((bf16_t)(u0 >> 16));
+                v0[2] += bf2f((bf16_t)(u1 & 0xffffu)); v0[3] += bf2f((bf16_t)(u1 >> 16));
+                v1[0] += bf2f((bf16_t)(u2 & 0xffffu)); v1[1] += bf2f((bf16_t)(u2 >> 16));
+                v1[2] += bf2f((bf16_t)(u3 & 0xffffu)); v1[3] += bf2f((bf16_t)(u3 >> 16));
+            }
+        } else if (s < 8) {
+            if (s == 1) { v0[0] = silu_f<false>(v0[0]); v0[1] = silu_f<false>(v0[1]); }
+            if (s == 2) v0[2] = silu_f<false>(v0[2]);
+            if (s == 3) v0[3] = silu_f<false>(v0[3]);
+            if (s == 4) v1[0] = silu_f<false>(v1[0]);
+            if (s == 5) v1[1] = silu_f<false>(v1[1]);
+            if (s == 6) v1[2] = silu_f<false>(v1[2]);
+            if (s == 7) v1[3] = silu_f<false>(v1[3]);
+        } else {
+            const int row = rowP + j;                      // band relative
+            if (!CONS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int t0 = ld[0][q], t1 = ld[1][q];
+                    v0[q] += u2f(t0);
+                    v1[q] += u2f(t1);
+                }
+                // y rows above / below the image are the zero padding of conv2
+                const bool inside = (unsigned)(y0 + row) < (unsigned)a.Hin;
+                u32x4 o;
+                o[0] = inside ? pack2(v0[0], v0[1]) : 0u;
+                o[1] = inside ? pack2(v0[2], v0[3]) : 0u;
+                o[2] = inside ? pack2(v1[0], v1[1]) : 0u;
+                o[3] = inside ? pack2(v1[2], v1[3]) : 0u;
+                // y row index i = row + 1; channels co .. co+7 are 16-byte piece co/8 of the pixel: plane piece >> 1
+                const unsigned pc = (unsigned)co >> 3;
+                *(u32x4*)(yring + (pc >> 1) * RF_PLANE + (((row + 1) & 7) * 64 + colP + l15) * 32 + (pc & 1) * 16) = o;
+            } else {
+                u32x4 o;
+                o[0] = pack2(v0[0], v0[1]);
+                o[1] = pack2(v0[2], v0[3]);
+                o[2] = pack2(v1[0], v1[1]);
+                o[3] = pack2(v1[2], v1[3]);
+                store_out(a.out + (out_base + ((size_t)row * 64 + colP) * 64) * 2, o);
+            }
+        }
+    };
+
+    // One half: output rows r0, r0+1 (band relative) x the 16 columns from c0 of this wave's convolution.  ring: the
+    // ring it reads; jb: ring row index of window row 0 (the row above r0).  piece_q >= 0: the pair whose piece this
+    // half issues.  EPI: a previous half's epilogue is pending (it runs between the MFMAs).
+    // drain: the previous half issued no stores (it was this wave's first), so its residual loads are the youngest
+    // operations and the wait must be for everything.
+    auto do_half = [&](auto role_tag, auto half_tag, auto epi_tag, const char* ring, int jb, int r0, int c0, int piece_q,
+                       bool piece_live, bool drain) {
+        constexpr bool CONS = decltype(role_tag)::value;
+        constexpr int HALF = decltype(half_tag)::value ? 1 : 0;
+        constexpr bool EPI = decltype(epi_tag)::value;
+        // Vector-memory operations of a consumer half, in issue order: the DMA piece (f = 0), the residual row 0
+        // (f = 1), the store of the pending epilogue's row 0 (f = 10), the residual row 1 (f = 13), the store of row 1
+        // (f = 22).  Row 0 of the PREVIOUS half's residual is used at f = 0: three younger operations may still fly.
+        if (EPI && CONS) {
+            if (drain) wait_vmcnt<0>();
+            else wait_vmcnt<1>();
+#pragma unroll
+            for (int i = 0; i < HR; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+        }
+        f32x4 acc[NF][HR];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) acc[nf][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // addresses of the window rows and column shifts; a lane beside the image reads the zero pixel
+        unsigned rowb[HR + 2], pxo[3];
+        bool edge[3];
+#pragma unroll
+        for (int h = 0; h < HR + 2; ++h) rowb[h] = ((jb + h) & 7) * RF_ROWB + lane_po;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int px = c0 + l15 + dx - 1;
+            edge[dx] = (unsigned)px > 63u;
+            pxo[dx] = (unsigned)px * 32u;
+        }
+        constexpr int NFR = (HR + 2) * 6;
+        auto fr = [&](int f) -> const u32x4* {
+            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
+            const unsigned off = edge[dx] ? zpix : rowb[h] + pxo[dx];
+            return (const u32x4*)(ring + off + kk * 2 * RF_PLANE);
+        };
+        u32x4 xf[XD];
+#pragma unroll
+        for (int f = 0; f < XD - 1; ++f) xf[f] = *fr(f);
+        int slice = 0;
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+            if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *fr(f + XD - 1);
+            // memory work, one operation per fragment step: the DMA piece, then (consumers) the residual rows
+            if (f == (CONS ? 2 : 0)) issue_piece(piece_q, HALF, piece_live);
+            if (EPI && f % 4 != 3) epi_slice(role_tag, slice);
+            if (f % 4 != 3) ++slice;
+            if (CONS && f < 2) {
+                // this half's residual row f into its staging row, which was read back at the top
+                const int i = f;
+                asm volatile("" ::: "memory");
+                glds16(a.in0 + (out_base + ((size_t)(r0 + i) * 64 + c0) * 64) * 2, stage + i * 1024);
+                asm volatile("" ::: "memory");
+            }
+            const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = h - dy;
+                if (r < 0 || r >= HR) continue;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[nf][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wreg[(dy * 3 + dx) * 2 + kk][nf]), __builtin_bit_cast(bf16x8, xf[f % XD]),
+                        acc[nf][r], 0, 0, 0);
+            }
+            if (f + XD - 1 < NFR) {
+                if (h == 0 || h == HR + 1) __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) accP[nf][r] = acc[nf][r];
+        rowP = r0;
+        colP = c0;
+    };
+    auto flush_epilogue = [&](auto role_tag) {      // the epilogue of the last half of a role
+        if (decltype(role_tag)::value) {
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int i = 0; i < HR; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) epi_slice(role_tag, s);
+    };
+    // end of a step: the pieces of the previous step have landed (this step's two may still fly, consumers also keep
+    // their last two stores in flight: vmcnt retires in order, so "at most N outstanding" covers everything older),
+    // the y rows written in this step are in LDS, and every wave is done with the rows the next step overwrites
+    auto step_end = [&](int in_flight) {
+        // in_flight: how many of this wave's youngest operations, all issued in this step, may still fly
+        if (in_flight >= 8) wait_vmcnt<8>();
+        else wait_vmcnt<2>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    RF_STAMP(1);
+    const int c_first = wf * 32;
+    // the two roles run the same loop, each compiled for itself (no role test around a hand-written load)
+    auto run = [&](auto role_tag) {
+        constexpr bool CONS = decltype(role_tag)::value;
+        bool pending = false;
+        for (int k = 0; k < RF_NS; ++k) {
+            const int pq = k + 3;                               // the pair issued in this step
+            const bool plive = pq <= QMAX;
+            const bool active = CONS ? k >= RF_LAG : k < RF_NPROD;
+            if (!active) {
+                if (pending) {                                  // producers after their last step
+                    flush_epilogue(role_tag);
+                    pending = false;
+                }
+                issue_piece(pq, 0, plive);
+                issue_piece(pq, 1, plive);
+                step_end(2);
+                RF_STAMP(2 + k);
+                continue;
+            }
+            // producers: y rows 2k-1, 2k from the x rows 2k-2 .. 2k+1 = ring rows 2k .. 2k+3;
+            // consumers: output rows o, o+1 (o = 2(k - LAG)) from the y rows o-1 .. o+2 = ring rows o .. o+3
+            const int o = 2 * (k - RF_LAG);
+            const char* ring = CONS ? yring : xring;
+            const int jb = CONS ? o : 2 * k;
+            const int r0 = CONS ? o : 2 * k - 1;
+            if (!pending) do_half(role_tag, BoolC<false>{}, BoolC<false>{}, ring, jb, r0, c_first, pq, plive, false);
+            else do_half(role_tag, BoolC<false>{}, BoolC<true>{}, ring, jb, r0, c_first, pq, plive, false);
+            do_half(role_tag, BoolC<true>{}, BoolC<true>{}, ring, jb, r0, c_first + 16, pq, plive, !pending);
+            pending = true;
+            // a consumer step issues ten operations (per half: two residual rows, the piece, two stores); the
+            // youngest eight start with the first half's piece
+            step_end(CONS && k > RF_LAG ? 8 : 2);
+            RF_STAMP(2 + k);
+        }
+        if (pending) flush_epilogue(role_tag);
+    };
+    if (consumer) run(BoolC<true>{});
+    else run(BoolC<false>{});
+    RF_STAMP(2 + RF_NS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2301,6 +2666,36 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
 bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, int Win) {
     return dtype == LDM_BF16 && cin == 128 && cskip == 64 && cout == 64 && Hin % 4 == 0 && Win % 16 == 0 &&
            (long)B * (Hin / 4) * (Win / 16) >= 256 && (size_t)Hin * Win * 256 * 4 < (1ull << 31) && !TAPCONV_NO_WS64;
+}
+
+// ResidualBlock as one kernel: the shapes resfuse64_kernel serves (64 channels, 64-pixel-wide images whose height
+// is a multiple of the band, enough bands to fill the chip)
+bool resfuse_shape_ok(int dtype, int C, int B, int H, int W) {
+    return dtype == LDM_BF16 && C == 64 && W == 64 && H % RF_R == 0 && (long)B * (H / RF_R) >= 128 && B > 0 &&
+           (long)B * H * W * 64 * 2 < (1l << 40);
+}
+
+int launch_resfuse(const PackedConv& c1, const PackedConv& c2, const void* x, void* out, int B, int H, int W,
+                   const float* tvec, int t_img_stride, int t_step_stride, const int* step_ptr, hipStream_t stream) {
+    LDM_REQUIRE(x && out && tvec && c1.w && c1.bias && c2.w && c2.bias && x != out, "null or aliased tensor");
+    LDM_REQUIRE(c1.kind == CONV3x3_S1 && c2.kind == CONV3x3_S1 && c1.cin == 64 && c1.cout == 64 && c2.cin == 64 && c2.cout == 64 &&
+                    c1.dtype == c2.dtype && resfuse_shape_ok(c1.dtype, 64, B, H, W),
+                "shape not served by the fused ResidualBlock kernel");
+    TapConvArgs a{};
+    a.in0 = (const char*)x; a.out = (char*)out;
+    a.w = (const char*)c1.w; a.bias = c1.bias;
+    a.w2 = (const char*)c2.w; a.bias2 = c2.bias;
+    a.tvec = tvec; a.t_img_stride = t_img_stride; a.t_step_stride = t_step_stride; a.step_ptr = step_ptr;
+    a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.cout = 64;
+#ifdef TAPCONV_STAMP
+    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
+    static bool lds_set[kMaxDevices] = {};
+    LDM_TRY(allow_dynamic_lds((const void*)resfuse64_kernel, 160 * 1024, lds_set));
+    g_last_kernel = "ldm::resfuse64_kernel(ldm::TapConvArgs)";
+    hipLaunchKernelGGL(resfuse64_kernel, dim3((unsigned)(B * (H / RF_R))), dim3(512), RF_LDS, stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
 }
 
 // pc: packed by pack_conv as CONVT4x4_S2 over the sources {128 composed input channels, 64 skip channels},

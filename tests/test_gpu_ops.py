@@ -94,6 +94,39 @@ def test_resblock(A, O, dtype, C, B, H, W):
     assert e < TOL[dtype]
 
 
+@pytest.mark.parametrize("B,H", [(32, 64), (33, 64), (64, 32), (128, 16), (64, 64)])
+def test_resblock_fused_kernel(A, O, B, H):
+    """64 channels, bf16, 64-pixel-wide images and at least 128 bands of 16 rows: the ResidualBlock runs as ONE kernel
+    (conv1 + SiLU + t in LDS, conv2 + residual + SiLU).  Against the CPU restatement, and against the two-launch path,
+    which the same module takes for batches below that size (same arithmetic per image: bf16 intermediate, the same
+    order of accumulation)."""
+    from diffusionmodel_amd import _lib
+    from diffusionmodel_amd.weights import resblock_param_shapes, synthetic_from_shapes
+    W = 64
+    w = synthetic_from_shapes(resblock_param_shapes(64, 256), 13)
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, 64, H, W, generator=g)
+    t = torch.randn(B, 256, generator=g)
+    _say(f"fused resblock B={B} H={H}")
+    m = A.ResiduelBlock(64, 256, dtype="bf16", weights=w)
+    got = m(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert _lib.load().ldm_last_kernel().decode().startswith("ldm::resfuse64_kernel")
+    n = min(B, 8)                                        # the restatement on a few images, first and last
+    idx = list(range(n // 2)) + list(range(B - n // 2, B))
+    ref = O.residual_block({"m." + k: v for k, v in w.items()}, "m", x[idx], t[idx])
+    e = rel_err(got[idx], ref)
+    _say(f"  vs restatement rel_err={e:.3e}")
+    assert e < TOL["bf16"]
+    step = max(1, 96 // (H // 16))                       # chunks below 128 bands take the two launches
+    parts = torch.cat([m(x[i:i + step].cuda().contiguous(), t[i:i + step].cuda().contiguous()) for i in range(0, B, step)])
+    torch.cuda.synchronize()
+    assert "resfuse" not in _lib.load().ldm_last_kernel().decode()
+    e2 = rel_err(got, parts)
+    _say(f"  vs two launches rel_err={e2:.3e} max={max_err(got, parts):.3e}")
+    assert e2 < 2e-3
+
+
 # ---- Attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,B,H,W", [(256, 2, 4, 4), (256, 2, 16, 16), (128, 1, 12, 20), (256, 1, 1, 1), (512, 1, 8, 8),

@@ -7,7 +7,7 @@ name=$1; flags=$2; shift 2 || true
 files=${@:-tapconv.hip}
 mkdir -p build/dev devlibs
 objs=""
-for f in tapconv.hip attention.hip elementwise.hip ldm_api.hip; do
+for f in tapconv.hip attention.hip elementwise.hip batchnorm.hip ldm_api.hip; do
     if [[ " $files " == *" $f "* ]]; then
         o=build/dev/${name}_${f%.hip}.o
         hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-result \
