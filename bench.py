@@ -125,6 +125,26 @@ def pmc_traffic(kernel_name, shape):
     return None
 
 
+PMC_SQ_CSV = "r03_pmc_sq_per_kernel.csv"
+
+
+def pmc_mfma_busy(kernel_name):
+    """Share of the matrix pipes' cycles with an MFMA in flight for `kernel_name`, from the committed SQ counter passes
+    (tools/pmc_sq.sh on the default workload's shapes: SQ_VALU_MFMA_BUSY_CYCLES over 4 SIMDs x 256 CUs x the dispatch's
+    active cycles, and the same against 2.4 GHz x the traced duration), or None when that kernel is not in the file."""
+    import csv
+    short = kernel_name.replace("void ldm::", "").replace("ldm::", "").replace("(TapConvArgs)", "")
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_SQ_CSV)) as f:
+            for r in csv.DictReader(f):
+                if r["kernel"].replace("(TapConvArgs)", "") == short and r["mfma_busy"]:
+                    return {"mfma_busy": float(r["mfma_busy"]), "mfma_busy_wall": float(r["mfma_busy_wall"] or 0.0),
+                            "issue": float(r["issue"] or 0.0), "wait": float(r["wait"] or 0.0), "source": "profiles/" + PMC_SQ_CSV}
+    except (OSError, ValueError, KeyError):
+        return None
+    return None
+
+
 def cpu_baseline():
     """CPU restatement (oracle) on the host cores, BASELINE config 1: 50-step DDPM, B = 4, f32, at 64x64 latents and
     at the reference's own 4x4; one warm-up chain, then the median of three timed whole chains."""
@@ -380,6 +400,12 @@ def main():
             conv_roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc_traffic(kname, shape),
                          "kernel": kname, "shape": shape, "avg_ms": kms, "flop_per_launch": kflop, "other_levels": levels}
+            if args.dtype == "bf16" and B == 64 and S == 64 and not args.scaled:
+                # counters are a separate, committed measurement (rocprofv3 --pmc cannot run inside this process):
+                # taken on exactly this kernel and shape
+                busy = pmc_mfma_busy(kname)
+                if busy:
+                    conv_roof.update(busy)
             if args.sampler == "ddpm" and args.dtype != "bf16":
                 # config 5: the scheduler update is the HBM-bound kernel of the path
                 sms, sbytes = time_sched_kernel(B, S, cfg.in_channels)

@@ -42,102 +42,33 @@
 #include <type_traits>
 #include <utility>
 
-// Developer-only timing ablations (never set in the shipped build): 1 no MFMA, 2 no weight DMA in
-// the loop, 4 no LDS reads and no MFMA, 8 no epilogue stores, 16 no halo DMA, 32 one weight fragment read per half step,
-// 64 every second window fragment read per half step (32 and 64 keep everything else, results are wrong: timing only).
+// Development builds only (-DLDM_DEV_BUILD, tools/devbuild.sh): timing ablations that compile parts of a kernel out
+// (wrong results) and cycle stamps.  The shipped library contains none of it.
+//   TAPCONV_ABLATE (generic kernel): 1 no MFMA, 2 no weight DMA in the loop, 4 no LDS reads and no MFMA, 8 no epilogue
+//     stores, 16 no halo DMA, 32 one weight fragment read per half step, 64 every second window fragment read
+//   WS64_ABLATE (64-channel weight-stationary kernel): 1 no window DMA after the first tile, 2 no output stores, 4 no
+//     staging of the epilogue's inputs
+//   TAPCONV_STAMP: real-time stamps of workgroups / steps (tools/wglife.py, wslife.py, rflife.py, stamps.py)
+#ifndef LDM_DEV_BUILD
+#undef TAPCONV_ABLATE
+#undef WS64_ABLATE
+#undef TAPCONV_STAMP
+#endif
 #ifndef TAPCONV_ABLATE
 #define TAPCONV_ABLATE 0
 #endif
-// wave layout of the 8-row x 128-channel tile (tuning knob while measuring)
-#ifndef TAPCONV_NO_WS64
-#define TAPCONV_NO_WS64 0
-#endif
-// the same for the 64-channel weight-stationary kernel: 1 no window DMA after the first tile, 2 no output stores,
-// 4 no staging of the epilogue's inputs (wrong results: timing only)
 #ifndef WS64_ABLATE
 #define WS64_ABLATE 0
 #endif
-// epilogue inputs of the 64-channel weight-stationary kernel (residual rows, rows of the sampler state, time vector):
-// 1 = loaded straight into registers by asm loads with counted waits, 0 = staged through LDS by LDS-DMA
-#ifndef WS64_REGLOAD
-#define WS64_REGLOAD 0
-#endif
-#ifndef TAPCONV_WS_XD
-#define TAPCONV_WS_XD 4
-#endif
-#ifndef TAPCONV_EARLY
-#define TAPCONV_EARLY 0
-#endif
-#ifndef TAPCONV_1X1_RING
-#define TAPCONV_1X1_RING 2
-#endif
-#ifndef TAPCONV_RING_L1
-#define TAPCONV_RING_L1 3
-#endif
-#ifndef TAPCONV_RING_L2
-#define TAPCONV_RING_L2 3
-#endif
-#ifndef TAPCONV_L2_WM
-#define TAPCONV_L2_WM 8          // waves over the rows / channels of the 16-row x 128-channel tile (128-channel level, bf16)
-#define TAPCONV_L2_WN 2
-#endif
-#ifndef TAPCONV_UP_WM
-#define TAPCONV_UP_WM 8          // the same for the fused up-sampling block (x 2 waves over the channels)
-#endif
-#ifndef TAPCONV_RING_UP
-#define TAPCONV_RING_UP 3        // the fused up-sampling block at the 128-channel level (16 rows x 128 channels)
-#endif
-#ifndef TAPCONV_RING_L3
-#define TAPCONV_RING_L3 4
-#endif
-#ifndef TAPCONV_ALWAYS_ISSUE
-#define TAPCONV_ALWAYS_ISSUE 1
-#endif
-#ifndef TAPCONV_S2WS_128
-#define TAPCONV_S2WS_128 1
-#endif
-#ifndef TAPCONV_S2WS_128_NF
-#define TAPCONV_S2WS_128_NF 2
-#endif
-#ifndef SKINNY3_MAXWG_F32
-#define SKINNY3_MAXWG_F32 1024       // f32 3x3 convolutions with at most this many skinny workgroups take the skinny kernel
-#endif
-#ifndef TAPCONV_SKINNY_MAXM
-#define TAPCONV_SKINNY_MAXM 512      // 1x1 convolutions over at most this many pixels take the skinny kernel
-#endif
-#ifndef TAPCONV_DDIM_Z_PLAIN
-#define TAPCONV_DDIM_Z_PLAIN 1
-#define TAPCONV_DDIM_O_PLAIN 0
-#endif
-#ifndef TAPCONV_STATIC_WAITS
-#define TAPCONV_STATIC_WAITS 1
-#endif
-#ifndef TAPCONV_OUT_STORE
-#define TAPCONV_OUT_STORE 2      // 0 plain, 1 nontemporal, 2 sc1 (write-through, shipped), 3 sc0 sc1: see store_out
-#endif
-#ifndef TAPCONV_S2WS_NBUF
-#define TAPCONV_S2WS_NBUF 2
-#endif
-#ifndef TAPCONV_S2WS_128_KSPL
-#define TAPCONV_S2WS_128_KSPL 1  // 128 -> 256 stride 2: the two input chunks on two groups of waves (two waves per SIMD)
-#endif
-#ifndef TAPCONV_S2WS_EARLY
-#define TAPCONV_S2WS_EARLY 5
-#endif
-#ifndef TAPCONV_WS64_EARLY
-#define TAPCONV_WS64_EARLY 5
-#endif
-#ifndef TAPCONV_L3B_WN
-#define TAPCONV_L3B_WN 2         // waves over the 64 channels of the 16-row x 64-channel tile (256-channel level)
-#define TAPCONV_L3B_MINW 2
-#endif
-#ifndef TAPCONV_L3_WM
-#define TAPCONV_L3_WM 4
-#define TAPCONV_L3_WN 2
-#define TAPCONV_L3_MINW 2
-#endif
 
 namespace ldm {
+
+// Launch thresholds (measured cross-over points).
+constexpr long kSkinny3MaxWgF32 = 1024;   // f32 3x3 convolutions with at most this many skinny workgroups take the skinny kernel
+constexpr long kSkinny1x1MaxPix = 512;    // 1x1 convolutions over at most this many pixels take the skinny kernel
+// Persistent kernels with two workgroups per CU: eighths of a CU's tiles that its first-placed workgroup takes (the
+// second one's weights and first window land later; 5 : 3 measured best, 6 : 2 slower, results do not depend on it).
+constexpr int kEarlyEighths = 5;
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -229,26 +160,18 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// Output stores of the convolution kernels.  TAPCONV_OUT_STORE 2 = write-through (sc1): the bytes go to memory as the
-// kernel runs and the line is dropped from this XCD's L2, so a launch ends with nothing dirty to write back (a launch
-// that leaves B dirty bytes delays the next one by about B / 6 TB/s).  The instruction is written as asm so that the
-// cache bits are exactly these; like any store it counts once in vmcnt, in issue order, which the hand-counted waits
-// of the weight-stationary kernels rely on.  `s_nop 1` keeps the data registers intact until the store has read them.
+// Output stores of the convolution kernels are write-through (sc1): the bytes go to memory as the kernel runs and the
+// line is dropped from this XCD's L2, so a launch ends with nothing dirty to write back (a launch that leaves B dirty
+// bytes delays the next one by about B / 6 TB/s; plain stores measured 1-7 % slower per kernel in the sampler's graph,
+// nontemporal ones slower than plain).  The instruction is written as asm so that the cache bits are exactly these;
+// like any store it counts once in vmcnt, in issue order, which the hand-counted waits of the weight-stationary
+// kernels rely on.  `s_nop 1` keeps the data registers intact until the store has read them.  8-byte write-through
+// stores are one fabric write each (2.7 times the time per byte of a 16-byte one): those stay plain.
 template <typename V>
 __device__ __forceinline__ void store_out(char* p, const V& v) {
     static_assert(sizeof(V) == 16 || sizeof(V) == 8, "8- or 16-byte stores");
-#if TAPCONV_OUT_STORE == 2
-    // (8-byte write-through stores are one fabric write each, 2.7 times the time per byte of a 16-byte one: those stay plain)
     if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *(V*)p = v;
-#elif TAPCONV_OUT_STORE == 3
-    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif TAPCONV_OUT_STORE == 1
-    __builtin_nontemporal_store(v, (V*)p);
-#else
-    *(V*)p = v;
-#endif
 }
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body
@@ -505,13 +428,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
         }
     };
 
-    // Two schedules.  RING <= 3: the barrier at the end of step s publishes slab s+1, so the first reads
-    // of step s+1 can only be issued after it and their LDS latency is exposed once per step.
-    // EARLY (RING >= 4, more than one tap per chunk): the barrier publishes slab s+2 instead; the reads
-    // of step s+1's first half are then issued BEFORE the barrier, behind the MFMAs of step s, and the
-    // register double-buffering of fragments runs straight across the barrier.
-    constexpr bool EARLY = RING >= 4 && NTAPS > 1 && TAPCONV_EARLY;
-    constexpr int PUB = EARLY ? 2 : 1;           // the barrier of step s publishes slab s + PUB
+    // The barrier at the end of step s publishes slab s+1, so the first reads of step s+1 are issued after it.
+    // (Publishing slab s+2 instead, with the reads of step s+1 issued before the barrier, measured no faster.)
+    constexpr int PUB = 1;                       // the barrier of step s publishes slab s + PUB
 
     // prologue: halo 0, then slabs 0 .. D-1; wait for halo 0 and the slabs below PUB
     issue_halo(0);
@@ -533,7 +452,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
     // loop unrolled over constant indices and the last chunk as a second copy of the body, each step's wait is one
     // s_waitcnt with an immediate; computed at run time, the same counts were a tree of about ten scalar branches
     // between the step's last MFMA and its barrier.
-    constexpr bool STATIC_WAITS = TAPCONV_STATIC_WAITS && !SKIPUP && !EARLY && NTAPS > D && TAPCONV_ALWAYS_ISSUE && !(TAPCONV_ABLATE & 31);
+    constexpr bool STATIC_WAITS = !SKIPUP && NTAPS > D && !(TAPCONV_ABLATE & 31);
     if constexpr (STATIC_WAITS) {
         auto run_chunk = [&](int c, auto lastc_tag) {
             constexpr bool LASTC = decltype(lastc_tag)::value;
@@ -590,14 +509,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             STAMP_ISSUE(tsA);
             const bool halo_now = t == 0 && more_chunks;
             if (halo_now) issue_halo(c + 1);      // older than slab s+D: a later counted wait covers it
-#if TAPCONV_ALWAYS_ISSUE
             // Past the last slab the last one is issued again, into a ring slot that no later step reads: the
             // issue stays unconditional, so the second half of this step and the first half of the next are one
             // basic block (a branch here made the compiler wait for every LDS read in flight at the join).
             if (!(TAPCONV_ABLATE & 2)) issue_w(s + D < nsteps ? s + D : nsteps - 1, slot == 0 ? RING - 1 : slot - 1);
-#else
-            if (s + D < nsteps && !(TAPCONV_ABLATE & 2)) issue_w(s + D, slot == 0 ? RING - 1 : slot - 1);
-#endif
             const unsigned wb = wbuf0 + slot * WSLAB;
             const int slot_next = slot + 1 == RING ? 0 : slot + 1;
             // first half of the next step (after the very last step this reads LDS that nobody uses:
@@ -608,11 +523,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
                 load_frags(1, hb, wb, t, wfB, xfB);
                 mfma_batch(wfA, xfA);
                 interleave_reads_with_mfma();
-                if constexpr (EARLY) {
-                    load_frags(0, hbn, wbuf0 + slot_next * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
-                    mfma_batch(wfB, xfB);
-                    interleave_reads_with_mfma();
-                }
             }
             // What must have landed before the barrier: slab s+PUB and, if step s+PUB opens a chunk,
             // that chunk's halo.  Younger pieces may stay in flight: the later slabs that exist, and the
@@ -620,21 +530,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
             // s+PUB at step s+PUB-D) and step s+PUB still belongs to this chunk.
             const int need = s + PUB < nsteps - 1 ? s + PUB : nsteps - 1;
             const int last = s + D < nsteps - 1 ? s + D : nsteps - 1;
-#if TAPCONV_ALWAYS_ISSUE
             // repeated issues of the last slab are younger than everything needed; the last step drains the queue
             const int nrep = s + D + 1 - nsteps > 0 ? s + D + 1 - nsteps : 0;
             const int young = (TAPCONV_ABLATE & 2) || s == nsteps - 1 ? 0 : (last - need > 0 ? last - need : 0) + nrep;
-#else
-            const int young = (TAPCONV_ABLATE & 2) ? 0 : (last - need > 0 ? last - need : 0);
-#endif
             const bool h_young = more_chunks && t <= D - 1 - PUB && t <= ntc - 1 - PUB && !(TAPCONV_ABLATE & 16);
 #ifdef TAPCONV_STAMP
             STAMP_ISSUE(tsB);        // (waits for the LDS reads as a side effect)
 #endif
             wait_leaving(young, h_young);
-            // RING <= 3: this step's LDS reads are complete before any wave may overwrite what they
-            // read.  EARLY: a slot is overwritten a whole step after its last read was consumed.
-            if constexpr (!EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // this step's LDS reads are complete before any wave may overwrite what they read
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef TAPCONV_STAMP
             STAMP_ISSUE(tsC);
             STAMP_STORE(sidx, tsA); STAMP_STORE(sidx + 1, tsB); STAMP_STORE(sidx + 2, tsC);
@@ -642,7 +547,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tapconv_kernel(const TapCo
 #endif
             __builtin_amdgcn_s_barrier();
             slot = slot_next;
-            if constexpr (!(TAPCONV_ABLATE & 4) && !EARLY) {
+            if constexpr (!(TAPCONV_ABLATE & 4)) {
                 load_frags(0, hbn, wbuf0 + slot * WSLAB, wrap ? 0 : t + 1, wfA, xfA);
                 mfma_batch(wfB, xfB);
                 interleave_reads_with_mfma();
@@ -813,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     // LDS-DMA pieces per wave, 16 bytes per lane, read back by the same lane
     constexpr int NLDG = RES ? HR : (DDIM ? 2 * HR : (TV ? 2 : 0));
     constexpr int NST = DDIM ? 3 : 1;                                // stores per epilogue row
-    constexpr int XD = TAPCONV_WS_XD;                                // depth of the X fragment register ring
+    constexpr int XD = 4;                                            // depth of the X fragment register ring
     static_assert(NG == 6, "three halo pieces per half");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -911,9 +816,6 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     // needs, the time vector and the element offset of their first row
     f32x4 accP[NF][HR];
     u32x4 ldP[NLDG > 1 ? NLDG : 2];
-    // WS64_REGLOAD: the loads issued during a first half land in ldA, those of a second half in ldB; the epilogue
-    // of a half runs during the next one and reads the other set
-    u32x4 ldA[NLDG > 1 ? NLDG : 2], ldB[NLDG > 1 ? NLDG : 2];
     size_t eP = 0;
     char* stage = smem + 2 * HALO_BYTES + wave * (NLDG * 1024);      // wave-uniform: DMA destination base
     f32x4 v0, v1;          // the row that is passing through the epilogue slices
@@ -968,13 +870,10 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
                     z0[q] = ((z0[q] - v0[q] * k_s1m) * k_rsa) * k_c1 + v0[q] * k_c2;
                     z1[q] = ((z1[q] - v1[q] * k_s1m) * k_rsa) * k_c1 + v1[q] * k_c2;
                 }
-#if TAPCONV_DDIM_Z_PLAIN
+                // plain stores for the sampler's state and its bf16 copy: written through, this kernel took 56.7
+                // instead of 46.7 us (state) and the 50-step chain 0.35 % longer (copy)
                 *(f32x4*)(a.sched_z + eo) = z0;
                 *(f32x4*)(a.sched_z + eo + 4) = z1;
-#else
-                store_out((char*)(a.sched_z + eo), z0);
-                store_out((char*)(a.sched_z + eo + 4), z1);
-#endif
                 v0 = z0;
                 v1 = z1;
             }
@@ -984,12 +883,8 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
             o[2] = pack2(v1[0], v1[1]);
             o[3] = pack2(v1[2], v1[3]);
             if ((WS64_ABLATE & 2) && o[0] != 0x12345678u) return;
-#if TAPCONV_DDIM_O_PLAIN
             if constexpr (DDIM) *(u32x4*)(a.out + eo * 2) = o;
             else store_out(a.out + eo * 2, o);
-#else
-            store_out(a.out + eo * 2, o);
-#endif
         }
     };
 
@@ -1014,22 +909,11 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * 16;
         e0 = (((size_t)img * a.Hout + y0 + wm * 2 * HR) * a.Wout + x0 + l15) * 64 + co;
     };
-    // the epilogue inputs of the half that just ended become ldP; second_half: this half is a second half (the
-    // finished one was a first half).  Called after the counted wait that covers them.
-    auto read_staged = [&](bool second_half) {
-#if WS64_REGLOAD
-        // the registers were written by loads the compiler does not see: every later use hangs on this statement,
-        // which stands behind the wait
-#pragma unroll
-        for (int i = 0; i < NLDG; ++i) {
-            if (second_half) { asm volatile("" : "+v"(ldA[i])); ldP[i] = ldA[i]; }
-            else { asm volatile("" : "+v"(ldB[i])); ldP[i] = ldB[i]; }
-        }
-#else
-        (void)second_half;
+    // (Loading these rows straight into registers with hand-written loads instead of staging them through LDS
+    // measured the same in the SiLU modes and needs 16 more registers in the DDIM mode, which then spills.)
+    auto read_staged = [&]() {
 #pragma unroll
         for (int i = 0; i < NLDG; ++i) ldP[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
-#endif
     };
 
     // half_tag: second half of the tile; epi_tag: a previous half exists (its epilogue runs here);
@@ -1042,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
         if (EPI && NLDG > 0) {
             if (WAIT == 1) wait_vmcnt<2 * NST>();
             if (WAIT == 2) wait_vmcnt<0>();
-            read_staged(HALF == 1);
+            read_staged();
         }
         const size_t eC = e0 + HALF * HR * erow;
         f32x4 acc[NF][HR];
@@ -1073,14 +957,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
                 if (RES) src = a.res + (eC + i * erow) * 2;
                 else if (DDIM) src = (const char*)(a.sched_z + eC + (i >> 1) * erow + (i & 1) * 4);
                 else src = (const char*)(a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co + i * 4);
-#if WS64_REGLOAD
-                if (!(WS64_ABLATE & 4)) {
-                    if (HALF) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldB[i]) : "v"(src) : "memory");
-                    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldA[i]) : "v"(src) : "memory");
-                }
-#else
                 if (!(WS64_ABLATE & 4)) glds16(src, stage + i * 1024);
-#endif
             }
             // 18 epilogue slices over the 24 fragment steps (the stores fall on steps 10 and 22)
             if (EPI && f % 4 != 3) epi_slice(slice);
@@ -1128,7 +1005,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_ws64_kernel(const TapConvArgs 
     }
     // the last half's epilogue
     wait_vmcnt<0>();
-    read_staged(false);             // the last half was a second half: its inputs are in the other set
+    read_staged();
 #pragma unroll
     for (int s = 0; s < KS; ++s) epi_slice(s);
     WS_STAMP_END();
@@ -1208,6 +1085,25 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         *(u32x4*)(smem + ring * RF_RINGB + plane * RF_PLANE + RF_RING * RF_ROWB + sub * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
+    // x rows: pair q holds the band-relative rows 2q-2 and 2q-1 in the ring rows (2q & 7) and (2q & 7) + 1.  Its 16
+    // pieces (4 planes x 2 rows x 2 halves of a row) are issued by the 8 waves, two each: piece e = wave * 2 + i.
+    const size_t img_base = (size_t)img * a.Hin * 64;
+    auto issue_piece = [&](int q, int i, bool live) {
+        const int e = wave * 2 + i;
+        const int plane = e >> 2, rr = (e >> 1) & 1, hx = (e & 1) * 32 + (lane >> 1);
+        const int iy = y0 + 2 * q - 2 + rr;
+        const bool ok = live && (unsigned)iy < (unsigned)a.Hin;
+        const char* src = ok ? a.in0 + (img_base + (size_t)iy * 64 + hx) * 128 + plane * 32 + (lane & 1) * 16 : zero;
+        char* dst = live ? xring + plane * RF_PLANE + (((2 * q) & 7) + rr) * RF_ROWB + (e & 1) * 1024 : dump;
+        glds16(src, dst);
+    };
+    constexpr int QMAX = RF_NPROD;                          // the last producer step needs the pairs QMAX-1 and QMAX
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        issue_piece(q, 0, true);
+        issue_piece(q, 1, true);
+    }
+
     // this wave's 32 output channels of every (tap, half) of ITS convolution
     const char* wsrc = consumer ? a.w2 : a.w;
     u32x4 wreg[KS][NF];
@@ -1231,28 +1127,10 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         ld[0] = *(const u32x4*)tp;
         ld[1] = *(const u32x4*)(tp + 4);
     }
-    // the loads above are ordinary loads: they are complete before the first LDS-DMA piece is issued, so the counted
-    // waits below only ever see the pieces, the residual loads and the stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (ordinary loads, issued behind the first window's pieces so that the two latencies overlap; the wait for
+    // everything in front of the first barrier covers them, and the counted waits of the loop only ever see pieces,
+    // residual rows and stores)
 
-    // x rows: pair q holds the band-relative rows 2q-2 and 2q-1 in the ring rows (2q & 7) and (2q & 7) + 1.  Its 16
-    // pieces (4 planes x 2 rows x 2 halves of a row) are issued by the 8 waves, two each: piece e = wave * 2 + i.
-    const size_t img_base = (size_t)img * a.Hin * 64;
-    auto issue_piece = [&](int q, int i, bool live) {
-        const int e = wave * 2 + i;
-        const int plane = e >> 2, rr = (e >> 1) & 1, hx = (e & 1) * 32 + (lane >> 1);
-        const int iy = y0 + 2 * q - 2 + rr;
-        const bool ok = live && (unsigned)iy < (unsigned)a.Hin;
-        const char* src = ok ? a.in0 + (img_base + (size_t)iy * 64 + hx) * 128 + plane * 32 + (lane & 1) * 16 : zero;
-        char* dst = live ? xring + plane * RF_PLANE + (((2 * q) & 7) + rr) * RF_ROWB + (e & 1) * 1024 : dump;
-        glds16(src, dst);
-    };
-    constexpr int QMAX = RF_NPROD;                          // the last producer step needs the pairs QMAX-1 and QMAX
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        issue_piece(q, 0, true);
-        issue_piece(q, 1, true);
-    }
 
     // per-lane pieces of the fragment addresses: plane and half of the lane, pixel offsets of the three column shifts
     const unsigned lane_po = (g >> 1) * RF_PLANE + (g & 1) * 16;
@@ -1710,7 +1588,7 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
     // Windows in LDS: that of tile i + NBUF - 1 is issued during tile i.  Three fit (with the compact planes, also next to
     // the partial sums of the chunk split) and were measured: no faster per tile, and the two windows that every
     // workgroup then requests at the start delay the first tile (13.3 against 12.8 us for 128 -> 256 channels).
-    constexpr int NBUF = TAPCONV_S2WS_NBUF;
+    constexpr int NBUF = 2;
     static_assert(NBUF == 2 || NBUF == 3, "two or three windows");
     static_assert(NBUF * HALO_BYTES + (KSPL == 2 ? 2 * 8 * 2048 : 0) <= 160 * 1024, "LDS budget");
     constexpr int KS = NCH * 18, XD = 4, NFR = NCH * HH * 6;                     // 30 fragments per chunk and tile
@@ -1789,7 +1667,7 @@ __global__ __launch_bounds__(256 * KSPL, (NCH == 1 ? 2 : 1)) void s2ws_kernel(co
     };
     auto halo_piece = [&](int p, int buf) {
         const int c = p / NG, q = p % NG;                // c: chunk of this wave (compile time), on top of its group's first
-        const unsigned off = ((hinval >> (2 * q)) & 3u) ? 0xffffffffu : (unsigned)(horg + hoff[q] + c * 128);
+        const unsigned off = ((hinval >> (2 * q)) & 3u) ? 0x80000000u : (unsigned)(horg + hoff[q] + c * 128);   // beyond any image (< 2^31 bytes), and + 16 cannot wrap
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             hrsrc, (__attribute__((address_space(3))) void*)(smem + buf * HALO_BYTES + (kg * NCH + c) * CHUNK_BYTES + wave * HPLANE +
                                                              (q * 32 < HP - 32 ? q * 32 : HP - 32) * 32),
@@ -2395,13 +2273,11 @@ static int pick_th(long tiles16, long tiles8, int nblk_n, int nphase, long want,
     return 4;
 }
 
-// share of a pair's tiles that the first-placed workgroup takes, in eighths (0 = even split), per epilogue mode;
-// LDM_WS64_EARLY overrides it for measurements
-static int ws64_early_eighths(int mode) {
-    static const int env = [] { const char* e = getenv("LDM_WS64_EARLY"); return e ? atoi(e) : -1; }();
-    if (env >= 0) return env >= 8 ? 7 : env;
-    (void)mode;
-    return TAPCONV_WS64_EARLY;
+// Uneven shares for the two workgroups of a CU (kEarlyEighths of a pair's tiles for the first-placed one) need two
+// workgroups on every CU and at least two tiles in every pair: with a single tile both workgroups of the pair would
+// run it (the in-place DDIM update twice), with none the tile index goes negative.
+static int early_eighths(int grid, int ntiles, int ncu) {
+    return (grid == 2 * ncu && ntiles >= 2 * grid) ? kEarlyEighths : 0;
 }
 
 template <int MODE>
@@ -2419,8 +2295,8 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
     a.nblk_n = 1;
     const size_t lds = 2 * 6 * 4096 + 4 * 4 * 1024;  // two halo buffers of 10x18 pixels + staged epilogue inputs
     const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-    // uneven shares for the two workgroups of a CU once every pair has at least four tiles (see the kernel)
-    a.early_num = (grid == 2 * ncu && a.ntiles >= 4 * ncu) ? ws64_early_eighths(MODE) : 0;
+    a.early_num = early_eighths(grid, a.ntiles, ncu);
+    LDM_REQUIRE(a.early_num == 0 || a.ntiles >= 2 * grid, "uneven tile shares need two tiles per pair of workgroups");
     static const std::string name = "void ldm::tapconv_ws64_kernel<" + std::to_string(MODE) + ">(ldm::TapConvArgs)";
     g_last_kernel = name.c_str();
     hipLaunchKernelGGL(tapconv_ws64_kernel<MODE>, dim3(grid), dim3(256), lds, stream, a);
@@ -2432,25 +2308,21 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
 // one tile per workgroup slot of the chip.
 static bool ws64_shape(const PackedConv& pc, const TapConvArgs& a) {
     return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && a.nch0 == 1 && a.nch1 == 0 && a.cout == 64 &&
-           a.Hg % 8 == 0 && a.Wg % 16 == 0 && (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512 && !TAPCONV_NO_WS64;
+           a.Hg % 8 == 0 && a.Wg % 16 == 0 && (long)(a.Hg / 8) * (a.Wg / 16) * a.B >= 512;
 }
 
 bool tapconv_can_fuse_ddim(const PackedConv& pc, int B, int H, int W) {
     return pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S1 && pc.cin == 64 && pc.cout == 64 && H % 8 == 0 && W % 16 == 0 &&
-           (long)(H / 8) * (W / 16) * B >= 512 && !TAPCONV_NO_WS64;
+           (long)(H / 8) * (W / 16) * B >= 512;
 }
 
 static bool s2ws_shape(const PackedConv& pc, const TapConvArgs& a) {
     const bool c64 = a.nch0 == 1 && a.cout == 128, c128 = a.nch0 == 2 && a.cout == 256;
-    return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || (c128 && TAPCONV_S2WS_128)) && a.nch1 == 0 &&
+    return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV3x3_S2 && (c64 || c128) && a.nch1 == 0 &&
            a.Hin % 4 == 0 && a.Win % 32 == 0 && (long)(a.Hout / 2) * (a.Wout / 16) * a.B >= 512 &&
            // limits of fast_div and of the 32-bit offsets inside one image
            (long)a.B * (a.Hout / 2) * (a.Wout / 16) * (a.Hout / 2) * (a.Wout / 16) < (1l << 32) && (long)a.Hin * a.Win * a.cin0_bytes < (1l << 31) &&
-           !TAPCONV_NO_WS64;
-}
-static int s2ws_early_eighths() {
-    static const int env = [] { const char* e = getenv("LDM_S2WS_EARLY"); return e ? atoi(e) : -1; }();
-    return env >= 0 ? (env >= 8 ? 7 : env) : TAPCONV_S2WS_EARLY;
+           true;
 }
 static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
@@ -2466,16 +2338,18 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
     a.magic_tpi = div_magic(a.tiles_x * a.tiles_y);
     a.magic_tx = div_magic(a.tiles_x);
     if (a.nch0 == 1) {
-        const size_t lds = TAPCONV_S2WS_NBUF * 165 * 128;       // windows of 5 x 33 pixels
+        const size_t lds = 2 * 165 * 128;               // two windows of 5 x 33 pixels
         a.nblk_n = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-        a.early_num = (a.nblk_n == 2 * ncu && a.ntiles >= 4 * ncu) ? s2ws_early_eighths() : 0;
+        a.early_num = early_eighths(a.nblk_n, a.ntiles, ncu);
+        LDM_REQUIRE(a.early_num == 0 || a.ntiles >= 2 * a.nblk_n, "uneven tile shares need two tiles per pair of workgroups");
         g_last_kernel = "void ldm::s2ws_kernel<1, 2, 1>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2>), dim3(a.nblk_n), dim3(256), lds, stream, a);
-    } else if (TAPCONV_S2WS_128_KSPL) {
+    } else {
         // two chunks split over two groups of four waves: one workgroup of eight waves per CU, 128 output channels each
+        // (one group of four waves over both chunks, 64 or 128 channels per workgroup, measured slower)
         static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
         LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<1, 2, 2>, 160 * 1024, lds_set));
-        const size_t lds = TAPCONV_S2WS_NBUF * 2 * 165 * 128 + 2 * 8 * 2048;   // windows of two chunks + the partial sums of eight waves, twice
+        const size_t lds = 2 * 2 * 165 * 128 + 2 * 8 * 2048;   // two windows of two chunks + the partial sums of eight waves, twice
         const int ncb = a.cout / 128;
         int per = ncu / ncb;
         if (per < 1) per = 1;
@@ -2483,18 +2357,6 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
         a.nblk_n = per;
         g_last_kernel = "void ldm::s2ws_kernel<1, 2, 2>(ldm::TapConvArgs)";
         hipLaunchKernelGGL((s2ws_kernel<1, 2, 2>), dim3(per * ncb), dim3(512), lds, stream, a);
-    } else {
-        constexpr int NF128 = TAPCONV_S2WS_128_NF;       // 16-channel fragments per wave: a workgroup owns 64 * NF128 output channels
-        static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
-        LDM_TRY(allow_dynamic_lds((const void*)s2ws_kernel<2, NF128>, 160 * 1024, lds_set));
-        const size_t lds = TAPCONV_S2WS_NBUF * 2 * 165 * 128;   // windows of two chunks
-        const int ncb = a.cout / (64 * NF128);           // one workgroup per CU, the CUs split over the channel blocks
-        int per = ncu / ncb;
-        if (per < 1) per = 1;
-        if (per > a.ntiles) per = a.ntiles;
-        a.nblk_n = per;
-        g_last_kernel = NF128 == 2 ? "void ldm::s2ws_kernel<2, 2, 1>(ldm::TapConvArgs)" : "void ldm::s2ws_kernel<2, 1, 1>(ldm::TapConvArgs)";
-        hipLaunchKernelGGL((s2ws_kernel<2, NF128>), dim3(per * ncb), dim3(256), lds, stream, a);
     }
     LDM_HIP(hipGetLastError());
     return LDM_OK;
@@ -2503,7 +2365,7 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 static bool ws1x1_shape(const PackedConv& pc, const TapConvArgs& a) {
     const long px = (long)a.B * a.Hin * a.Win;
     return a.cin0_bytes == a.nch0 * 128 && pc.dtype == LDM_BF16 && pc.kind == CONV1x1 && a.nch0 == 4 && a.nch1 == 0 && a.cout % 256 == 0 && px % 32 == 0 &&
-           px / 32 >= 512 && !TAPCONV_NO_WS64;
+           px / 32 >= 512;
 }
 
 template <bool RES>
@@ -2579,13 +2441,13 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         // is as fast at one image and faster from four on, so bf16 takes this kernel only when LDM_SKINNY3_MAXWG says so.
         static const long maxwg = [] {       // read once per process (and element type)
             const char* e = getenv("LDM_SKINNY3_MAXWG");
-            return e ? atol(e) : (long)(sizeof(T) == 4 ? SKINNY3_MAXWG_F32 : 0);
+            return e ? atol(e) : (long)(sizeof(T) == 4 ? kSkinny3MaxWgF32 : 0);
         }();
         const long t64 = (long)((a.Wout + 15) / 16) * ((a.Hout + 3) / 4) * a.B;
         if (t64 <= 65535 && t64 * (a.cout / 16) <= maxwg) return launch_skinny3x3<T>(pc, a, stream);
     }
     // measured at 1024 -> 1024 channels: 145 vs 206 us per sampler step at 256 pixels, a tie at 1024, half the speed at 4096
-    if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= TAPCONV_SKINNY_MAXM) return launch_skinny1x1<T>(a, stream);
+    if (pc.kind == CONV1x1 && (long)a.B * a.Hin * a.Win <= kSkinny1x1MaxPix) return launch_skinny1x1<T>(a, stream);
     if constexpr (sizeof(T) == 2) {
         if (s2ws_shape(pc, a) && a.act == ACT_NONE && !a.res && !a.tvec && !a.out_f32) return launch_s2ws(a, stream);
         if (ws1x1_shape(pc, a) && a.act == ACT_NONE && !a.tvec && !a.out_f32)
@@ -2614,7 +2476,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
             return launch_cfg<T, 4, 128, 2, 2, 1, 1, 1, 1>(a, nph, stream);
         }
         if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 1, 1, 2>(a, nph, stream);
-        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 1, 2, TAPCONV_1X1_RING>(a, nph, stream);
+        if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 1, 1, 2, 2>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 1, 1, 1, 2>(a, nph, stream);
     }
     // 3x3-window kinds: conv3x3 stride 1 (9 taps) and the convT phases (4 taps)
@@ -2624,16 +2486,16 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if (bn == 128) {
             // too few 16-row tiles for 128-channel blocks: 16 rows x 64 channels moves a third fewer bytes
             // per CU through L2 -> LDS than 8 rows x 128 channels (weights halve, the window grows less)
-            if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, TAPCONV_L3B_WN, 1, 3, 9, TAPCONV_L3B_MINW, TAPCONV_RING_L3>(a, nph, stream);
+            if (th == 8 && a.Hg > 8 && t16 * (a.cout / 64) >= 256) return launch_cfg<T, 16, 64, 4, 2, 1, 3, 9, 2, 4>(a, nph, stream);
             // a launch of a single round of workgroups runs the tile with sixteen waves (four per SIMD cover each other's
             // barrier and DMA stalls: 24.1 -> 23.1 us at 256 workgroups); over many rounds eight waves are 1 % faster
             if (th == 16 && sizeof(T) == 2 && one_round)
-                return launch_cfg<T, 16, 128, TAPCONV_L2_WM, TAPCONV_L2_WN, 1, 3, 9, TAPCONV_L2_WM * TAPCONV_L2_WN / 4, TAPCONV_RING_L2>(a, nph, stream);
-            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, TAPCONV_RING_L2>(a, nph, stream);
-            if (th == 8) return launch_cfg<T, 8, 128, TAPCONV_L3_WM, TAPCONV_L3_WN, 1, 3, 9, TAPCONV_L3_MINW, TAPCONV_RING_L3>(a, nph, stream);
+                return launch_cfg<T, 16, 128, 8, 2, 1, 3, 9, 4, 3>(a, nph, stream);
+            if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 9, 2, 3>(a, nph, stream);
+            if (th == 8) return launch_cfg<T, 8, 128, 4, 2, 1, 3, 9, 2, 4>(a, nph, stream);
             return launch_cfg<T, 4, 128, 2, 2, 1, 3, 9, 1>(a, nph, stream);
         }
-        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 9, 2, TAPCONV_RING_L1>(a, nph, stream);
+        if (th == 16) return launch_cfg<T, 16, 64, 4, 1, 1, 3, 9, 2, 3>(a, nph, stream);
         if (th == 8) return launch_cfg<T, 8, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
         return launch_cfg<T, 4, 64, 2, 2, 1, 3, 9, 2>(a, nph, stream);
     }
@@ -2642,8 +2504,8 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
         if constexpr (sizeof(T) == 2) {
             if (pc.ntaps1 != 1 || !cc.in1) LDM_FAIL(LDM_ERR_INVALID, "fused up-sampling conv needs its skip source");
             if (bn == 128) {
-                if (th == 16 && one_round) return launch_cfg<T, 16, 128, TAPCONV_UP_WM, 2, 1, 3, 4, TAPCONV_UP_WM / 2, TAPCONV_RING_UP, 1>(a, nph, stream);   // 28.9 -> 26.3 us
-                if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, TAPCONV_RING_UP, 1>(a, nph, stream);
+                if (th == 16 && one_round) return launch_cfg<T, 16, 128, 8, 2, 1, 3, 4, 4, 3, 1>(a, nph, stream);   // 28.9 -> 26.3 us
+                if (th == 16) return launch_cfg<T, 16, 128, 4, 2, 1, 3, 4, 2, 3, 1>(a, nph, stream);
                 if (th == 8) return launch_cfg<T, 8, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
                 return launch_cfg<T, 4, 128, 2, 2, 1, 3, 4, 1, 3, 1>(a, nph, stream);
             }
@@ -2665,7 +2527,7 @@ static int launch_typed(const PackedConv& pc, const ConvCall& cc, TapConvArgs& a
 
 bool upfuse_shape_ok(int dtype, int cin, int cskip, int cout, int B, int Hin, int Win) {
     return dtype == LDM_BF16 && cin == 128 && cskip == 64 && cout == 64 && Hin % 4 == 0 && Win % 16 == 0 &&
-           (long)B * (Hin / 4) * (Win / 16) >= 256 && (size_t)Hin * Win * 256 * 4 < (1ull << 31) && !TAPCONV_NO_WS64;
+           (long)B * (Hin / 4) * (Win / 16) >= 256 && (size_t)Hin * Win * 256 * 4 < (1ull << 31);
 }
 
 // ResidualBlock as one kernel: the shapes resfuse64_kernel serves (64 channels, 64-pixel-wide images whose height

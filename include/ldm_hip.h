@@ -28,9 +28,8 @@
  *                          its choice).
  *   LDM_SKINNY3_MAXWG=n    3x3 convolutions with at most n skinny workgroups take the skinny kernel (default: 1024
  *                          in f32, 0 in bf16); read once per process.
- *   LDM_WS64_EARLY=e, LDM_S2WS_EARLY=e   eighths of a CU's tiles that the first-placed of its two workgroups takes in the
- *                          64-channel 3x3 and the 64 -> 128 stride-2 kernel (default 5; 0 = even split; results do not
- *                          depend on it); read once per process.
+ *   LDM_RESFUSE=0          run a ResidualBlock of the 64-channel level as its two convolution launches instead of the
+ *                          one fused kernel (same bits; comparison runs and tests); read once per process.
  */
 #ifndef LDM_HIP_H
 #define LDM_HIP_H

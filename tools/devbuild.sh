@@ -11,7 +11,7 @@ for f in tapconv.hip attention.hip elementwise.hip batchnorm.hip ldm_api.hip; do
     if [[ " $files " == *" $f "* ]]; then
         o=build/dev/${name}_${f%.hip}.o
         hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-result \
-              -Wno-unused-command-line-argument $flags -c diffusionmodel_amd/csrc/$f -o $o 2>&1 | grep -v "not a recognized feature" || true
+              -Wno-unused-command-line-argument -DLDM_DEV_BUILD $flags -c diffusionmodel_amd/csrc/$f -o $o 2>&1 | grep -v "not a recognized feature" || true
         test -f $o
         objs="$objs $o"
     else
