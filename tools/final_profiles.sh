@@ -16,7 +16,10 @@ for b in 32 128 256; do timeout -k 10 300 python3 bench.py --batch $b --steps 5 
 bash tools/pmc_traffic.sh $out/pmc > $out/pmc.log 2>&1
 python3 tools/pmc_traffic_json.py $out/pmc > $out/pmc_summary.txt
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
-for f in $out/*.json; do python3 - $f <<'PY'
+bash tools/pmc_sq.sh $out/pmc_sq > $out/pmc_sq.log 2>&1
+python3 tools/pmc_sq_csv.py $out/pmc_sq $out/pmc_sq_per_kernel.csv > $out/pmc_sq_summary.txt
+timeout -k 10 200 python3 tools/bnbench.py 64 > $out/bnbench.txt 2>&1
+for f in $out/*.json; do [ "$(basename $f)" = pmc_traffic.json ] && continue; python3 - $f <<'PY'
 import json, sys
 try:
     r = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])

@@ -17,4 +17,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     run l2 $ctr tools/convone.py conv3x3 64 32 128 128
     run l1 $ctr tools/convone.py conv3x3 64 64 64 64
     run sched $ctr tools/schedone.py 64 64 64
+    run rf $ctr tools/resone.py 64
 done

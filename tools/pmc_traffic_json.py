@@ -6,8 +6,11 @@ src = sys.argv[1]
 SHAPES = {"l3": ("3x3 256->256 on [64,16,16,256] bf16", 2 * 64 * 16 * 16 * 256 * 2 + 256 * 256 * 9 * 2),
           "l2": ("3x3 128->128 on [64,32,32,128] bf16", 2 * 64 * 32 * 32 * 128 * 2 + 128 * 128 * 9 * 2),
           "l1": ("3x3 64->64 on [64,64,64,64] bf16", 2 * 64 * 64 * 64 * 64 * 2 + 64 * 64 * 9 * 2),
-          "sched": ("[64,64,64,64] f32 ddpm", 16 * 64 * 64 * 64 * 64)}
-WANT = {"l3": "tapconv", "l2": "tapconv", "l1": "tapconv", "sched": "sched_step_kernel"}
+          "sched": ("[64,64,64,64] f32 ddpm", 16 * 64 * 64 * 64 * 64),
+          # the fused ResidualBlock: x in, block output out, two weight sets (its forward also converts NCHW <-> NHWC
+          # around the kernel; only the kernel's own launches are averaged)
+          "rf": ("ResidualBlock 64 channels on [64,64,64,64] bf16", 2 * 64 * 64 * 64 * 64 * 2 + 2 * 64 * 64 * 9 * 2)}
+WANT = {"l3": "tapconv", "l2": "tapconv", "l1": "tapconv", "sched": "sched_step_kernel", "rf": "resfuse64_kernel"}
 def avg(name, ctr):
     files = glob.glob(os.path.join(src, f"{name}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
     assert files, (name, ctr)
