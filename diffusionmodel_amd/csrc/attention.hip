@@ -331,10 +331,22 @@ struct AttnFuseArgs {
     const float* bias;
     const char* xres;
 };
-template <int D, int QF, int NW, bool FUSE = false>
+// MODE of the streaming kernel:
+//   AT_PLAIN  qkv = [B, N, 3D] (q | k | v), out = O
+//   AT_WO     the same input; out = O Wo + bias + x (FUSE below)
+//   AT_FOLD   the projections folded at pack time (pack_attention): the scores only depend on x_i (Wq Wk^T) x_j^T +
+//             (Wk bq) . x_j (terms that are constant along the keys cancel in the soft-max), and P (x Wv + bv) Wo + bo =
+//             P (x Wv Wo) + (bv Wo + bo) because the rows of P sum to one.  So qkv = [B, N, 2D] (q' | v') with
+//             q' = x (Wq Wk^T) + Wk bq and v' = x (Wv Wo), the KEYS ARE THE BLOCK'S INPUT x ITSELF (fa.xres, [B, N, D]),
+//             and out = O + (bv Wo + bo) + x: no key projection, no output projection.
+enum { AT_PLAIN = 0, AT_WO = 1, AT_FOLD = 2 };
+template <int D, int QF, int NW, int MODE = AT_PLAIN>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
                                                                   int N, float scale_log2e, int B, AttnFuseArgs fa) {
+    constexpr bool FUSE = MODE == AT_WO, FOLD = MODE == AT_FOLD;
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
+    // row strides of the query, key and value matrices
+    constexpr int QSTR = FOLD ? 2 * RB : 3 * RB, KSTR = FOLD ? RB : 3 * RB, VSTR = FOLD ? 2 * RB : 3 * RB;
     // ring depth: four stages where they fit (C = 256), else two (C = 512: a stage is 64 KiB)
     constexpr int TILE = KT * RB, NPIECE = TILE / 1024, NST = 4 * 2 * TILE <= 160 * 1024 ? 4 : 2;
     constexpr int QB = NW * QF * 16, PPT = NPIECE / NW, PPW = 2 * PPT;
@@ -354,7 +366,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     if (b >= B) return;                      // (the grid is padded to a multiple of eight images)
     AT_STAMP(0);
     const int q0 = ((int)(blockIdx.x >> 3) % nqb) * QB + wave * QF * 16;
-    const char* base = qkv + (size_t)b * N * 3 * RB;
+    const char* base = qkv + (size_t)b * N * QSTR;
+    const char* kbase = FOLD ? fa.xres + (size_t)b * N * RB : base + RB;
+    const char* vbase = base + (FOLD ? RB : 2 * RB);
     const int ntiles = N / KT;
     constexpr int NWT = FUSE ? D / KT : 0;             // tiles of Wo^T behind the key/value tiles
     const int ntot = ntiles + NWT;
@@ -369,19 +383,19 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     {
         const int o = wave * 1024 + lane * 16;
         const int r = o / RB, sp = (o - r * RB) >> 4;
-        koff = r * 3 * RB + RB + ((sp ^ (r & 15)) << 4);
-        voff = r * 3 * RB + 2 * RB + ((sp ^ ((r & 7) << 1)) << 4);
+        koff = r * KSTR + ((sp ^ (r & 15)) << 4);
+        voff = r * VSTR + ((sp ^ ((r & 7) << 1)) << 4);
     }
     auto issue_tile = [&](int t) {
         char* kd = smem + (t & (NST - 1)) * 2 * TILE + wave * 1024;
-        const char* src = base + (size_t)t * KT * 3 * RB;
+        const char* ksrc = kbase + (size_t)t * KT * KSTR;
+        const char* vsrc = vbase + (size_t)t * KT * VSTR;
         unsigned ko = koff, vo = voff;
         asm volatile("" : "+v"(ko), "+v"(vo));   // opaque: no per-piece 64-bit addresses kept across iterations
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const char* sj = src + (size_t)j * RPJ * 3 * RB;
-            at_glds16(sj + (ko ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
-            at_glds16(sj + (vo ^ ((unsigned)((j * RPJ) & 7) << 5)), kd + TILE + j * NW * 1024);
+            at_glds16(ksrc + (size_t)j * RPJ * KSTR + (ko ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
+            at_glds16(vsrc + (size_t)j * RPJ * VSTR + (vo ^ ((unsigned)((j * RPJ) & 7) << 5)), kd + TILE + j * NW * 1024);
         }
     };
     // tile t >= ntiles: rows 32 (t - ntiles) .. of Wo^T into the K half of the stage (PPT pieces per wave, same swizzle)
@@ -400,10 +414,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         for (int j = 0; j < PPT; ++j)
             at_glds16(src + (size_t)j * RPJ * RB + (wo_ ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
     };
-    constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FUSE: the bias vector behind the ring (D floats)
-    if constexpr (FUSE) {
-        static_assert(D * 4 <= 1024, "the bias is one DMA piece");
-        if (wave == 0 && lane < D / 4) at_glds16((const char*)(fa.bias + lane * 4), smem + BIAS_OFF);
+    constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FUSE / FOLD: the bias vector behind the ring (D floats)
+    if constexpr (FUSE || FOLD) {
+        static_assert(D * 4 <= 2048, "the bias is one DMA piece of one or two waves");
+        if (wave < (D * 4 + 1023) / 1024 && wave * 64 + lane < D / 4)
+            at_glds16((const char*)(fa.bias + (wave * 64 + lane) * 4), smem + BIAS_OFF + wave * 1024);
     }
 
     // Issue order of the prologue: the bias, Q and the residual first, then the first tiles.  vmcnt retires in issue
@@ -411,16 +426,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     u32x4 qreg[QF][KS];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        const char* row = base + (size_t)(q0 + qf * 16 + l15) * 3 * RB;
+        const char* row = base + (size_t)(q0 + qf * 16 + l15) * QSTR;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qreg[qf][ks] = *(const u32x4*)(row + (ks * 4 + g) * 16);
     }
-    // FUSE: the residual of this lane's outputs (query l15 of the wave, channels 32 j + 16 kf + 4 g .. + 3), loaded with Q
-    uint2 xr[FUSE ? NWT * 2 : 1];
-    if constexpr (FUSE) {
+    // FUSE: the residual of this lane's outputs (query l15 of the wave, channels 32 j + 16 kf + 4 g .. + 3), loaded with Q.
+    // FOLD at 16 queries per wave and 256 channels: the same bytes (channels 16 df + 4 g .. + 3); the other instances have
+    // no registers for them and load the residual in the epilogue.
+    constexpr bool XR_EARLY = FUSE || (FOLD && QF == 1 && D <= 256);
+    constexpr int NXR = FUSE ? NWT * 2 : DF;
+    uint2 xr[XR_EARLY ? NXR : 1];
+    if constexpr (XR_EARLY) {
         const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + g * 8;
 #pragma unroll
-        for (int i = 0; i < NWT * 2; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
+        for (int i = 0; i < NXR; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
     }
     asm volatile("" ::: "memory");
     constexpr int NPRO = NST >= 3 ? NST - 1 : 1;       // tiles issued before the first interval
@@ -435,9 +454,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qreg[qf][ks]));
-    if constexpr (FUSE) {
+    if constexpr (XR_EARLY) {
 #pragma unroll
-        for (int i = 0; i < NWT * 2; ++i) asm volatile("" : "+v"(xr[i]));
+        for (int i = 0; i < NXR; ++i) asm volatile("" : "+v"(xr[i]));
     }
 
     f32x4 oacc[DF][QF];
@@ -655,6 +674,45 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         return;
     }
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
+    if constexpr (FOLD) {
+        // out = O / l + (bv Wo + bo) + x, in f32, rounded once
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            float l = lrun[qf];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            int qi = q0 + qf * 16 + l15;
+            asm volatile("" : "+v"(qi));     // the addresses are formed here, not ahead of the tile loop (where they spill)
+            const size_t ro = ((size_t)b * N + qi) * RB + g * 8;
+            // (residual loaded here: eight fragments at a time, the accumulators leave no room for all of them)
+            constexpr int GRP = XR_EARLY ? DF : 8;
+#pragma unroll
+            for (int d0 = 0; d0 < DF; d0 += GRP) {
+                uint2 xl[GRP];
+                if constexpr (!XR_EARLY) {
+#pragma unroll
+                    for (int i = 0; i < GRP; ++i) xl[i] = *(const uint2*)(fa.xres + ro + (d0 + i) * 32);
+                }
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int df = d0 + i;
+                    const f32x4 bv = *(const f32x4*)(smem + BIAS_OFF + (df * 16 + g * 4) * 4);
+                    const uint2 r = XR_EARLY ? xr[XR_EARLY ? df : 0] : xl[i];
+                    f32x4 v = oacc[df][qf] * inv + bv;
+                    v[0] += __builtin_bit_cast(float, r.x << 16);
+                    v[1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, r.y << 16);
+                    v[3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
+                    uint2 w;
+                    w.x = at_pack2(v[0], v[1]);
+                    w.y = at_pack2(v[2], v[3]);
+                    *(uint2*)(out + ro + df * 32) = w;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
         float l = lrun[qf];
@@ -673,12 +731,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     }
 }
 
-template <int D, int QF, int NW, bool FUSE = false>
+template <int D, int QF, int NW, int MODE = AT_PLAIN>
 static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream, AttnFuseArgs fa = AttnFuseArgs{}) {
     constexpr int QB = NW * QF * 16;
     constexpr size_t stage = (size_t)2 * 32 * D * 2;
-    constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage + (FUSE ? 1024 : 0);
-    auto kern = attention_stream_kernel<D, QF, NW, FUSE>;
+    constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage + (MODE != AT_PLAIN ? 2048 : 0);
+    auto kern = attention_stream_kernel<D, QF, NW, MODE>;
     static bool lds_set[kMaxDevices] = {};   // per kernel (instantiation) and device
     LDM_TRY(allow_dynamic_lds((const void*)kern, 160 * 1024, lds_set));
     LDM_REQUIRE(N % QB == 0, "token count must be a multiple of the query block");
@@ -721,7 +779,34 @@ int launch_attention_fused(const void* qkv, const void* wo_packed, const float* 
     LDM_REQUIRE(qkv && wo_packed && bias && xres && out && B > 0 && N > 0, "bad arguments");
     LDM_REQUIRE(B <= 65535 && attention_can_fuse_out(LDM_BF16, B, N, C), "shape not served by the fused attention kernel");
     AttnFuseArgs fa{(const char*)wo_packed, bias, (const char*)xres};
-    return launch_attn_stream<256, 1, 4, true>(qkv, out, B, N, stream, fa);
+    return launch_attn_stream<256, 1, 4, AT_WO>(qkv, out, B, N, stream, fa);
+}
+
+// The shapes the folded form serves: bf16 and the token counts that take an instance of the streaming kernel.
+// LDM_ATTN_FOLD=0 (developer switch, read at every call like LDM_DENSE4) keeps the unfolded projections, which gives the
+// parity tests a second GPU implementation of the block to compare with.
+static int fold_instance(int B, int N, int C) {
+    if (C == 256) {
+        if (N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256) return 1;
+        if (N % 64 == 0 && (long)B * ((N + 127) / 128) < 256) return 2;
+    } else if (C == 512) {
+        if (N % 128 == 0 && N >= 512 && (long)B * (N / 128) >= 256) return 3;
+    }
+    return 0;
+}
+bool attention_can_fold(int dtype, int B, int N, int C) {
+    const char* e = getenv("LDM_ATTN_FOLD");
+    return !(e && e[0] == '0') && dtype == LDM_BF16 && B > 0 && B <= 65535 && N > 0 && fold_instance(B, N, C) != 0;
+}
+int launch_attention_folded(const void* qv, const void* x, const float* bias, void* out, int B, int N, int C, hipStream_t stream) {
+    LDM_REQUIRE(qv && x && bias && out && B > 0 && N > 0, "bad arguments");
+    LDM_REQUIRE(attention_can_fold(LDM_BF16, B, N, C), "shape not served by the folded attention kernel");
+    AttnFuseArgs fa{nullptr, bias, (const char*)x};
+    switch (fold_instance(B, N, C)) {
+        case 1: return launch_attn_stream<256, 2, 8, AT_FOLD>(qv, out, B, N, stream, fa);
+        case 2: return launch_attn_stream<256, 1, 4, AT_FOLD>(qv, out, B, N, stream, fa);
+        default: return launch_attn_stream<512, 1, 8, AT_FOLD>(qv, out, B, N, stream, fa);
+    }
 }
 
 int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C, hipStream_t stream) {

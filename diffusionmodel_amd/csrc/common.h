@@ -159,6 +159,10 @@ int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C,
 bool attention_can_fuse_out(int dtype, int B, int N, int C);
 int launch_attention_fused(const void* qkv, const void* wo_packed, const float* bias, const void* xres, void* out, int B, int N,
                            int C, hipStream_t stream);
+// Attention with the projections folded at pack time (see attention_stream_kernel, AT_FOLD): qv = [B, N, 2C] bf16
+// (q' | v'), x = the block's input [B, N, C] (keys and residual), bias = bv Wo + bo (f32 [C]).
+bool attention_can_fold(int dtype, int B, int N, int C);
+int launch_attention_folded(const void* qv, const void* x, const float* bias, void* out, int B, int N, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Bandwidth-bound kernels.

@@ -230,6 +230,10 @@ struct AttnP {
     PackedConv qkv, out;
     int C = 0;
     void* wo_t = nullptr;   // out.weight transposed [C][C] bf16 in the order of launch_attention_fused (bf16, C = 256 only)
+    // bf16, C = 256 / 512: the projections folded (launch_attention_folded): q' | v' as one 1x1 convolution C -> 2C with
+    // q' = x (Wq Wk^T) + Wk bq, v' = x (Wv Wo), and the constant bv Wo + bo that joins the residual
+    PackedConv qv;
+    float* fold_bias = nullptr;
 };
 
 struct UnetBufs {   // NHWC activation buffers of one forward at fixed (B, H, W)
@@ -524,6 +528,42 @@ static int pack_attention(ldm_module* m, const std::string& prefix, int C, AttnP
                 wt[(size_t)co * C + p] = host_f2bf((*wo)[(size_t)ci * C + co]);
             }
         LDM_TRY(m->pool.upload(&ap->wo_t, wt.data(), wt.size() * 2));
+    }
+    if (m->dtype == LDM_BF16 && (C == 256 || C == 512)) {
+        // Linear weights are [d_in, d_out].  Composed in double precision:
+        //   q_i . k_j = (x_i Wq + bq) . (x_j Wk + bk) = x_i (Wq Wk^T) x_j^T + (Wk bq) . x_j + (terms without j)
+        //   (P (x Wv + 1 bv^T)) Wo + bo = P (x (Wv Wo)) + (bv Wo + bo)          (the rows of P sum to one)
+        std::vector<double> a((size_t)C * C), vo((size_t)C * C), aq(C), bf(C);
+        for (int ci = 0; ci < C; ++ci)
+            for (int c = 0; c < C; ++c) {
+                double sa = 0.0, sv = 0.0;
+                for (int mm = 0; mm < C; ++mm) {
+                    sa += (double)(*wq)[(size_t)ci * C + mm] * (double)(*wk)[(size_t)c * C + mm];
+                    sv += (double)(*wv)[(size_t)ci * C + mm] * (double)(*wo)[(size_t)mm * C + c];
+                }
+                a[(size_t)ci * C + c] = sa;
+                vo[(size_t)ci * C + c] = sv;
+            }
+        for (int c = 0; c < C; ++c) {
+            double sq = 0.0, sb = (*bo)[c];
+            for (int mm = 0; mm < C; ++mm) {
+                sq += (double)(*bq)[mm] * (double)(*wk)[(size_t)c * C + mm];
+                sb += (double)(*bv)[mm] * (double)(*wo)[(size_t)mm * C + c];
+            }
+            aq[c] = sq;
+            bf[c] = sb;
+        }
+        PackSpec sf;
+        sf.kind = CONV1x1;
+        sf.dtype = m->dtype;
+        sf.cout = 2 * C;
+        sf.src = {C};
+        sf.w = [&](int, int, int co, int ci) { return (float)(co < C ? a[(size_t)ci * C + co] : vo[(size_t)ci * C + co - C]); };
+        sf.bias = [&](int co) { return co < C ? (float)aq[co] : 0.f; };
+        LDM_TRY(pack_conv(sf, m->pool, &ap->qv, nullptr));
+        std::vector<float> bff(C);
+        for (int c = 0; c < C; ++c) bff[c] = (float)bf[c];
+        LDM_TRY(m->pool.upload((void**)&ap->fold_bias, bff.data(), bff.size() * 4));
     }
     return LDM_OK;
 }
@@ -904,6 +944,10 @@ static int run_resblock_train(const ResBlockP& rp, int dtype, const void* x, voi
 // Attention::forward (src/main.rs:256-276): qkv projection, soft-max attention, out projection + x
 static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, void* att, void* out, int B, int H, int W,
                          hipStream_t st) {
+    if (ap.fold_bias && attention_can_fold(dtype, B, H * W, ap.C)) {
+        LDM_TRY(run_conv(ap.qv, x, ap.C, nullptr, 0, qkv, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+        return launch_attention_folded(qkv, x, ap.fold_bias, out, B, H * W, ap.C, st);
+    }
     LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     if (ap.wo_t && attention_can_fuse_out(dtype, B, H * W, ap.C))
         return launch_attention_fused(qkv, ap.wo_t, ap.out.bias, x, out, B, H * W, ap.C, st);

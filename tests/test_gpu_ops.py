@@ -175,6 +175,40 @@ def test_attention_at_the_scaled_unet_token_counts(A, O, dtype, C, B, H, W):
     assert e_branch < (5e-4 if dtype == "fp32" else 3e-2)
 
 
+# The bf16 block at 256 / 512 channels runs with its projections folded at pack time (keys = the block's input, no output
+# projection: q' = x (Wq Wk^T) + Wk bq, v' = x (Wv Wo), constant bv Wo + bo).  LDM_ATTN_FOLD=0 keeps the reference's
+# four Linears, a second GPU implementation of the same block: the two must agree with each other and with the oracle.
+# Shapes: the three instances of the streaming kernel (four waves x 16 queries incl. a batch that is no multiple of 8 and
+# fewer key tiles than ring stages; eight waves x 32 queries; 512 channels).
+@pytest.mark.parametrize("C,B,H,W", [(256, 64, 16, 16), (256, 9, 8, 16), (256, 3, 8, 8), (256, 64, 32, 32), (512, 64, 16, 32)])
+def test_attention_folded_projections_match_the_unfolded_kernels(A, O, C, B, H, W):
+    import os
+    from diffusionmodel_amd.weights import attention_param_shapes, synthetic_from_shapes
+    w = synthetic_from_shapes(attention_param_shapes(C), 11)
+    torch.manual_seed(7)
+    x = torch.randn(B, C, H, W) * 2.0
+    ref = O.attention({"m." + k: v for k, v in w.items()}, "m", x)
+    mod = A.Attention(C, dtype="bf16", weights=w)
+    _say(f"attention folded / unfolded bf16 C={C} {B}x{H}x{W}")
+    old = os.environ.get("LDM_ATTN_FOLD")
+    try:
+        os.environ.pop("LDM_ATTN_FOLD", None)
+        folded = mod(x.cuda()).cpu()
+        os.environ["LDM_ATTN_FOLD"] = "0"
+        plain = mod(x.cuda()).cpu()
+    finally:
+        if old is None:
+            os.environ.pop("LDM_ATTN_FOLD", None)
+        else:
+            os.environ["LDM_ATTN_FOLD"] = old
+    ef, ep = rel_err(folded - x, ref - x), rel_err(plain - x, ref - x)
+    ed = rel_err(folded - x, plain - x)
+    _say(f"  branch rel_err folded={ef:.3e} unfolded={ep:.3e} folded vs unfolded={ed:.3e}")
+    assert not torch.equal(folded, plain)      # the switch did select two implementations
+    assert ef < 3e-2 and ep < 3e-2 and ed < 3e-2
+    assert rel_err(folded, ref) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("spike_at", [5, 600, 1023])
 def test_attention_running_max_jump_long_sequence(A, O, spike_at):
     """The same property on the long-sequence kernel (bf16, 1024 tokens, 64 images)."""
