@@ -258,6 +258,11 @@ __global__ __launch_bounds__(256, MINB) void attention_kernel(const char* __rest
     }
 }
 
+// write-through 16-byte output store (the convolution kernels' store_out): nothing dirty is left in this XCD's L2 for
+// the end of the launch to write back
+__device__ __forceinline__ void at_store_out(char* p, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 template <int N_>
 __device__ __forceinline__ void at_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -279,6 +284,16 @@ __device__ __forceinline__ uint2 at_lds_read_tr16(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+// A global load that the compiler does not track: it waits for a tracked load with vmcnt(0) at the first use, which
+// would also drain every tile DMA issued behind it (that is what stood in front of the first interval: Q, and with it
+// the three tiles of the prologue).  The caller pairs it with at_wait_vmcnt<N>() and at_landed(value) before the first use.
+template <int OFF>
+__device__ __forceinline__ u32x4 at_gload128(const char* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void at_landed(u32x4& v) { asm volatile("" : "+v"(v)); }
 template <int N_>
 __device__ __forceinline__ void at_wait_lgkm(u32x4& v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N_));
@@ -426,17 +441,24 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     u32x4 qreg[QF][KS];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        const char* row = base + (size_t)(q0 + qf * 16 + l15) * QSTR;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qreg[qf][ks] = *(const u32x4*)(row + (ks * 4 + g) * 16);
+        const char* row = base + (size_t)(q0 + qf * 16 + l15) * QSTR + g * 16;
+        at_static_for<KS>([&](auto kc) { qreg[qf][decltype(kc)::value] = at_gload128<decltype(kc)::value * 64>(row); });
     }
     // FUSE: the residual of this lane's outputs (query l15 of the wave, channels 32 j + 16 kf + 4 g .. + 3), loaded with Q.
-    // FOLD at 16 queries per wave and 256 channels: the same bytes (channels 16 df + 4 g .. + 3); the other instances have
-    // no registers for them and load the residual in the epilogue.
+    // FOLD: the epilogue swaps the odd 16-lane rows of accumulator 2p with the even rows of accumulator 2p + 1
+    // (v_permlane16_swap, as the convolution kernels do), after which this lane owns the 8 consecutive channels
+    // 16 (2p + (g & 1)) + 8 (g >> 1) .. + 7 of query l15: residual loads and output stores are 16 bytes.  At 16 queries
+    // per wave and 256 channels the residual is loaded here, BEHIND the first tiles (it is needed last: in front of them
+    // every workgroup's first tile queued behind 16 KiB of residual); the other instances have no registers for it
+    // and load it in the epilogue.
     constexpr bool XR_EARLY = FUSE || (FOLD && QF == 1 && D <= 256);
-    constexpr int NXR = FUSE ? NWT * 2 : DF;
-    uint2 xr[XR_EARLY ? NXR : 1];
-    if constexpr (XR_EARLY) {
+    constexpr bool XR_LATE = FOLD && XR_EARLY;
+    constexpr int NXR = FUSE ? NWT * 2 : DF / 2;            // FUSE: 8-byte pieces, FOLD: 16-byte pieces
+    constexpr int NXRV = XR_LATE ? NXR : 0;                 // vector-memory operations behind the prologue tiles
+    uint2 xr[FUSE ? NXR : 1];
+    u32x4 xq[XR_LATE ? NXR : 1];
+    const unsigned fold_co = (g & 1) * 16 + (g >> 1) * 8;   // FOLD: first channel of this lane inside a fragment pair
+    if constexpr (FUSE) {
         const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + g * 8;
 #pragma unroll
         for (int i = 0; i < NXR; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
@@ -448,13 +470,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         if (t < ntiles) issue_tile(t);
         else if (FUSE) issue_wtile(t);
     asm volatile("" ::: "memory");
-    // a use of the loaded registers: the compiler waits for the loads here and not at the top of the
-    // tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
-#pragma unroll
-    for (int qf = 0; qf < QF; ++qf)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qreg[qf][ks]));
-    if constexpr (XR_EARLY) {
+    if constexpr (XR_LATE) {
+        const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + fold_co * 2;
+        at_static_for<NXR>([&](auto ic) { xq[decltype(ic)::value] = at_gload128<decltype(ic)::value * 64>(xrow); });
+        asm volatile("" ::: "memory");
+    }
+    if constexpr (FUSE) {
+        // a use of the loaded registers: the compiler waits for the (tracked) residual loads here and not at the top of
+        // the tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
 #pragma unroll
         for (int i = 0; i < NXR; ++i) asm volatile("" : "+v"(xr[i]));
     }
@@ -590,7 +613,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             }
         } else if (t3 < ntiles) {
             issue_tile(t3);
-            at_wait_vmcnt<2 * PPW>();
+            // (the late residual loads sit between the prologue tiles and tile NPRO: while tile t+1 is a prologue tile
+            // they are younger than it and may stay in flight too)
+            if (NXRV > 0 && t + 1 < NPRO) at_wait_vmcnt<2 * PPW + NXRV>();
+            else at_wait_vmcnt<2 * PPW>();
         } else if (FUSE && t3 < ntot) {
             issue_wtile(t3);
             if (t2 < ntiles) at_wait_vmcnt<PPW + PPT>();
@@ -607,8 +633,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 
     // the first tile (and everything older); the younger tiles of the prologue stay in flight where they are key/value
     // tiles (with fewer key tiles than ring stages the prologue also holds tiles of Wo^T: then wait for all)
-    if (NST >= 3 && ntiles >= NPRO) at_wait_vmcnt<(NPRO - 1) * PPW>();
+    if (NST >= 3 && ntiles >= NPRO) at_wait_vmcnt<(NPRO - 1) * PPW + NXRV>();
     else at_wait_vmcnt<0>();
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) at_landed(qreg[qf][ks]);     // (Q is older than every tile)
     __builtin_amdgcn_s_barrier();
     AT_STAMP(1);
 
@@ -675,7 +705,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     }
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
     if constexpr (FOLD) {
-        // out = O / l + (bv Wo + bo) + x, in f32, rounded once
+        // out = O / l + (bv Wo + bo) + x, in f32, rounded once; 16-byte write-through stores
+        if constexpr (XR_LATE) {
+            at_wait_vmcnt<0>();
+#pragma unroll
+            for (int i = 0; i < NXR; ++i) at_landed(xq[i]);
+        }
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             float l = lrun[qf];
@@ -684,33 +719,45 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             const float inv = 1.0f / l;
             int qi = q0 + qf * 16 + l15;
             asm volatile("" : "+v"(qi));     // the addresses are formed here, not ahead of the tile loop (where they spill)
-            const size_t ro = ((size_t)b * N + qi) * RB + g * 8;
-            // (residual loaded here: eight fragments at a time, the accumulators leave no room for all of them)
-            constexpr int GRP = XR_EARLY ? DF : 8;
+            const size_t ro = ((size_t)b * N + qi) * RB + fold_co * 2;
+            // (residual loaded here: four pairs at a time, the accumulators leave no room for all of them)
+            constexpr int GRP = XR_LATE ? NXR : 4;
 #pragma unroll
-            for (int d0 = 0; d0 < DF; d0 += GRP) {
-                uint2 xl[GRP];
-                if constexpr (!XR_EARLY) {
+            for (int p0 = 0; p0 < DF / 2; p0 += GRP) {
+                u32x4 xl[GRP];
+                if constexpr (!XR_LATE) {
 #pragma unroll
-                    for (int i = 0; i < GRP; ++i) xl[i] = *(const uint2*)(fa.xres + ro + (d0 + i) * 32);
+                    for (int i = 0; i < GRP; ++i) xl[i] = *(const u32x4*)(fa.xres + ro + (p0 + i) * 64);
                 }
 #pragma unroll
                 for (int i = 0; i < GRP; ++i) {
-                    const int df = d0 + i;
-                    const f32x4 bv = *(const f32x4*)(smem + BIAS_OFF + (df * 16 + g * 4) * 4);
-                    const uint2 r = XR_EARLY ? xr[XR_EARLY ? df : 0] : xl[i];
-                    f32x4 v = oacc[df][qf] * inv + bv;
-                    v[0] += __builtin_bit_cast(float, r.x << 16);
-                    v[1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
-                    v[2] += __builtin_bit_cast(float, r.y << 16);
-                    v[3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
-                    uint2 w;
-                    w.x = at_pack2(v[0], v[1]);
-                    w.y = at_pack2(v[2], v[3]);
-                    *(uint2*)(out + ro + df * 32) = w;
+                    const int p = p0 + i;
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned int, oacc[2 * p][qf][r] * inv),
+                                                                         __builtin_bit_cast(unsigned int, oacc[2 * p + 1][qf][r] * inv),
+                                                                         false, false);
+                        v0[r] = at_u2f(sw[0]);
+                        v1[r] = at_u2f(sw[1]);
+                    }
+                    const char* bp = smem + BIAS_OFF + (p * 32 + fold_co) * 4;
+                    v0 += *(const f32x4*)bp;
+                    v1 += *(const f32x4*)(bp + 16);
+                    const u32x4 r = XR_LATE ? xq[XR_LATE ? p : 0] : xl[i];
+                    v0[0] += at_u2f(r[0] << 16); v0[1] += at_u2f(r[0] & 0xffff0000u);
+                    v0[2] += at_u2f(r[1] << 16); v0[3] += at_u2f(r[1] & 0xffff0000u);
+                    v1[0] += at_u2f(r[2] << 16); v1[1] += at_u2f(r[2] & 0xffff0000u);
+                    v1[2] += at_u2f(r[3] << 16); v1[3] += at_u2f(r[3] & 0xffff0000u);
+                    const u32x4 w = {at_pack2(v0[0], v0[1]), at_pack2(v0[2], v0[3]), at_pack2(v1[0], v1[1]), at_pack2(v1[2], v1[3])};
+                    at_store_out(out + ro + p * 64, w);
                 }
             }
         }
+#ifdef ATTN_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AT_STAMP(6);
+#endif
         return;
     }
 #pragma unroll
