@@ -323,16 +323,6 @@ __device__ __forceinline__ void at_static_for(F&& f) {
 #ifndef ATTN_STREAM_SMALL
 #define ATTN_STREAM_SMALL 1
 #endif
-#ifndef ATTN_FUSE_OUT
-#define ATTN_FUSE_OUT 1
-#endif
-// FUSE: the output projection of Attention and the residual add (src/main.rs:271-275) run in the same kernel.  The
-// normalised O of a wave's queries stays in registers as the B operand of a second product Y^T = Wo^T O^T, whose A
-// operand (rows = output channels) streams through the K half of the same ring stages as D/32 more tiles: the
-// arithmetic of the score phase with Wo^T in the place of K and O in the place of Q.  An accumulator register holds
-// O^T[d = 16 df + 4 g + r]; the B fragment of 32-channel block ks is made of accumulators 2 ks and 2 ks + 1, so its
-// element j of lane group g is channel 32 ks + (j < 4 ? 4 g + j : 16 + 4 g + j - 4): `wo` holds Wo^T [D][D] with the
-// input channels of every block of 32 in that order (pack_attention).  xres / out: [B, N, D]; bias f32 [D].
 // Diagnostic builds (-DATTN_STAMP): 100-MHz real-time stamps of every workgroup of the streaming kernel, eight slots
 // each (start, first tiles landed, end of the key/value tiles, end), into the buffer whose address LDM_DBG_RT_PTR names.
 #ifdef ATTN_STAMP
@@ -341,24 +331,22 @@ static __device__ unsigned long long* g_attn_rt = nullptr;
 #else
 #define AT_STAMP(k_) do { } while (0)
 #endif
-struct AttnFuseArgs {
-    const char* wo;
+struct AttnFuseArgs {      // AT_FOLD: the constant vector (f32 [D]) and the block's input (keys, residual)
     const float* bias;
     const char* xres;
 };
 // MODE of the streaming kernel:
 //   AT_PLAIN  qkv = [B, N, 3D] (q | k | v), out = O
-//   AT_WO     the same input; out = O Wo + bias + x (FUSE below)
 //   AT_FOLD   the projections folded at pack time (pack_attention): the scores only depend on x_i (Wq Wk^T) x_j^T +
 //             (Wk bq) . x_j (terms that are constant along the keys cancel in the soft-max), and P (x Wv + bv) Wo + bo =
 //             P (x Wv Wo) + (bv Wo + bo) because the rows of P sum to one.  So qkv = [B, N, 2D] (q' | v') with
 //             q' = x (Wq Wk^T) + Wk bq and v' = x (Wv Wo), the KEYS ARE THE BLOCK'S INPUT x ITSELF (fa.xres, [B, N, D]),
 //             and out = O + (bv Wo + bo) + x: no key projection, no output projection.
-enum { AT_PLAIN = 0, AT_WO = 1, AT_FOLD = 2 };
+enum { AT_PLAIN = 0, AT_FOLD = 1 };
 template <int D, int QF, int NW, int MODE = AT_PLAIN>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
                                                                   int N, float scale_log2e, int B, AttnFuseArgs fa) {
-    constexpr bool FUSE = MODE == AT_WO, FOLD = MODE == AT_FOLD;
+    constexpr bool FOLD = MODE == AT_FOLD;
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
     // row strides of the query, key and value matrices
     constexpr int QSTR = FOLD ? 2 * RB : 3 * RB, KSTR = FOLD ? RB : 3 * RB, VSTR = FOLD ? 2 * RB : 3 * RB;
@@ -385,9 +373,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     const char* kbase = FOLD ? fa.xres + (size_t)b * N * RB : base + RB;
     const char* vbase = base + (FOLD ? RB : 2 * RB);
     const int ntiles = N / KT;
-    constexpr int NWT = FUSE ? D / KT : 0;             // tiles of Wo^T behind the key/value tiles
-    const int ntot = ntiles + NWT;
-    static_assert(!FUSE || (QF == 1 && NST >= 3), "the fused projection is written for 16 queries per wave and the four-stage ring");
 
     // DMA pieces of this wave: piece i = wave + NW j covers the RPP rows from row i * RPP of the tile; piece j
     // lies j * NW * RPP rows below piece 0, which changes the row swizzle by an XOR on bits that piece 0's row
@@ -413,75 +398,44 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             at_glds16(vsrc + (size_t)j * RPJ * VSTR + (vo ^ ((unsigned)((j * RPJ) & 7) << 5)), kd + TILE + j * NW * 1024);
         }
     };
-    // tile t >= ntiles: rows 32 (t - ntiles) .. of Wo^T into the K half of the stage (PPT pieces per wave, same swizzle)
-    unsigned woff = 0;
-    if constexpr (FUSE) {
-        const int o = wave * 1024 + lane * 16;
-        const int r = o / RB, sp = (o - r * RB) >> 4;
-        woff = r * RB + ((sp ^ (r & 15)) << 4);
-    }
-    auto issue_wtile = [&](int t) {
-        char* kd = smem + (t & (NST - 1)) * 2 * TILE + wave * 1024;
-        const char* src = fa.wo + (size_t)(t - ntiles) * KT * RB;
-        unsigned wo_ = woff;
-        asm volatile("" : "+v"(wo_));
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            at_glds16(src + (size_t)j * RPJ * RB + (wo_ ^ ((unsigned)((j * RPJ) & 15) << 4)), kd + j * NW * 1024);
-    };
-    constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FUSE / FOLD: the bias vector behind the ring (D floats)
-    if constexpr (FUSE || FOLD) {
+    constexpr unsigned BIAS_OFF = NST * 2 * TILE;      // FOLD: the constant vector bv Wo + bo behind the ring (D floats)
+    if constexpr (FOLD) {
         static_assert(D * 4 <= 2048, "the bias is one DMA piece of one or two waves");
         if (wave < (D * 4 + 1023) / 1024 && wave * 64 + lane < D / 4)
             at_glds16((const char*)(fa.bias + (wave * 64 + lane) * 4), smem + BIAS_OFF + wave * 1024);
     }
 
-    // Issue order of the prologue: the bias, Q and the residual first, then the first tiles.  vmcnt retires in issue
-    // order, so the wait in front of the first interval can leave the pieces of the second and third tile in flight.
+    // Issue order of the prologue: the bias, Q, the first tiles, then the residual.  vmcnt retires in issue order, so the
+    // wait in front of the first interval leaves the second and third tile (and the residual) in flight.  Q and the
+    // residual are loads the compiler does not track (at_gload128): its own wait for a tracked load is vmcnt(0).
     u32x4 qreg[QF][KS];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
         const char* row = base + (size_t)(q0 + qf * 16 + l15) * QSTR + g * 16;
         at_static_for<KS>([&](auto kc) { qreg[qf][decltype(kc)::value] = at_gload128<decltype(kc)::value * 64>(row); });
     }
-    // FUSE: the residual of this lane's outputs (query l15 of the wave, channels 32 j + 16 kf + 4 g .. + 3), loaded with Q.
     // FOLD: the epilogue swaps the odd 16-lane rows of accumulator 2p with the even rows of accumulator 2p + 1
     // (v_permlane16_swap, as the convolution kernels do), after which this lane owns the 8 consecutive channels
     // 16 (2p + (g & 1)) + 8 (g >> 1) .. + 7 of query l15: residual loads and output stores are 16 bytes.  At 16 queries
     // per wave and 256 channels the residual is loaded here, BEHIND the first tiles (it is needed last: in front of them
     // every workgroup's first tile queued behind 16 KiB of residual); the other instances have no registers for it
     // and load it in the epilogue.
-    constexpr bool XR_EARLY = FUSE || (FOLD && QF == 1 && D <= 256);
-    constexpr bool XR_LATE = FOLD && XR_EARLY;
-    constexpr int NXR = FUSE ? NWT * 2 : DF / 2;            // FUSE: 8-byte pieces, FOLD: 16-byte pieces
+    constexpr bool XR_LATE = FOLD && QF == 1 && D <= 256;
+    constexpr int NXR = DF / 2;                             // 16-byte pieces of a query's residual
     constexpr int NXRV = XR_LATE ? NXR : 0;                 // vector-memory operations behind the prologue tiles
-    uint2 xr[FUSE ? NXR : 1];
     u32x4 xq[XR_LATE ? NXR : 1];
     const unsigned fold_co = (g & 1) * 16 + (g >> 1) * 8;   // FOLD: first channel of this lane inside a fragment pair
-    if constexpr (FUSE) {
-        const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + g * 8;
-#pragma unroll
-        for (int i = 0; i < NXR; ++i) xr[i] = *(const uint2*)(xrow + i * 32);
-    }
     asm volatile("" ::: "memory");
     constexpr int NPRO = NST >= 3 ? NST - 1 : 1;       // tiles issued before the first interval
 #pragma unroll
     for (int t = 0; t < NPRO; ++t)
         if (t < ntiles) issue_tile(t);
-        else if (FUSE) issue_wtile(t);
     asm volatile("" ::: "memory");
     if constexpr (XR_LATE) {
         const char* xrow = fa.xres + ((size_t)b * N + q0 + l15) * RB + fold_co * 2;
         at_static_for<NXR>([&](auto ic) { xq[decltype(ic)::value] = at_gload128<decltype(ic)::value * 64>(xrow); });
         asm volatile("" ::: "memory");
     }
-    if constexpr (FUSE) {
-        // a use of the loaded registers: the compiler waits for the (tracked) residual loads here and not at the top of
-        // the tile loop, where its vmcnt(0) would also drain the tile DMA of every iteration
-#pragma unroll
-        for (int i = 0; i < NXR; ++i) asm volatile("" : "+v"(xr[i]));
-    }
-
     f32x4 oacc[DF][QF];
 #pragma unroll
     for (int df = 0; df < DF; ++df)
@@ -593,7 +547,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
     };
     // End of interval t: every wave is past barrier t-1, so stage (t-1) % 4 is free for tile t+3.  The barrier that
     // follows publishes tile t+1, the next one to be read: this wave waits for its pieces of THAT tile and leaves the
-    // pieces of tiles t+2 and t+3 in flight (a key/value tile is PPW pieces per wave, a tile of Wo^T PPT), so a tile has
+    // pieces of tiles t+2 and t+3 in flight (a key/value tile is PPW pieces per wave), so a tile has
     // two intervals to land.  (Waiting for tile t+2 here as well made every interval one memory latency long: 1.3 us
     // per 32 keys at 256 tokens, where an interval's arithmetic is a quarter of that.)
     // Only in the four-wave instance (one wave per SIMD, short sequences): the eight-wave instances are bound by their
@@ -605,9 +559,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             if (t3 < ntiles) {
                 issue_tile(t3);
                 at_wait_vmcnt<PPW>();
-            } else if (FUSE && t3 < ntot) {
-                issue_wtile(t3);
-                at_wait_vmcnt<PPT>();
             } else {
                 at_wait_vmcnt<0>();
             }
@@ -617,22 +568,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
             // they are younger than it and may stay in flight too)
             if (NXRV > 0 && t + 1 < NPRO) at_wait_vmcnt<2 * PPW + NXRV>();
             else at_wait_vmcnt<2 * PPW>();
-        } else if (FUSE && t3 < ntot) {
-            issue_wtile(t3);
-            if (t2 < ntiles) at_wait_vmcnt<PPW + PPT>();
-            else at_wait_vmcnt<2 * PPT>();
         } else if (t2 < ntiles) {
             at_wait_vmcnt<PPW>();
-        } else if (FUSE && t2 < ntot) {
-            at_wait_vmcnt<PPT>();
         } else {
             at_wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
     };
 
-    // the first tile (and everything older); the younger tiles of the prologue stay in flight where they are key/value
-    // tiles (with fewer key tiles than ring stages the prologue also holds tiles of Wo^T: then wait for all)
+    // the first tile (and everything older); the younger tiles of the prologue stay in flight
     if (NST >= 3 && ntiles >= NPRO) at_wait_vmcnt<(NPRO - 1) * PPW + NXRV>();
     else at_wait_vmcnt<0>();
 #pragma unroll
@@ -664,45 +608,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
         }
     }
 
-    if constexpr (FUSE) {
-        // ---- normalise, round O to bf16 (as the unfused path stores it) and project: Y = O Wo + bias + x ----
-        float l = lrun[0];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        const float inv = 1.0f / l;
-        u32x4 obf[1][KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const f32x4 lo = oacc[2 * ks][0] * inv, hi = oacc[2 * ks + 1][0] * inv;
-            obf[0][ks] = u32x4{at_pack2(lo[0], lo[1]), at_pack2(lo[2], lo[3]), at_pack2(hi[0], hi[1]), at_pack2(hi[2], hi[3])};
-        }
-        char* orow = out + ((size_t)b * N + q0 + l15) * RB;
-#pragma unroll
-        for (int j = 0; j < NWT; ++j) {
-            s_phase(ntiles + j, obf);                       // sacc[kf][0] = Y^T[32 j + 16 kf + 4 g + r][query l15]
-#pragma unroll
-            for (int kf = 0; kf < KF; ++kf) {
-                const int co = j * 32 + kf * 16 + g * 4;
-                const f32x4 bv = *(const f32x4*)(smem + BIAS_OFF + co * 4);
-                const uint2 r = xr[j * 2 + kf];
-                f32x4 v = sacc[kf][0] + bv;
-                v[0] += __builtin_bit_cast(float, r.x << 16);
-                v[1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
-                v[2] += __builtin_bit_cast(float, r.y << 16);
-                v[3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
-                uint2 w;
-                w.x = at_pack2(v[0], v[1]);
-                w.y = at_pack2(v[2], v[3]);
-                *(uint2*)(orow + co * 2) = w;
-            }
-            tail(ntiles + j);
-        }
-#ifdef ATTN_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        AT_STAMP(6);
-#endif
-        return;
-    }
     // ---- normalise and store: lane holds d = df*16 + g*4 + (0..3) of query q0 + qf*16 + l15 ----
     if constexpr (FOLD) {
         // out = O / l + (bv Wo + bo) + x, in f32, rounded once; 16-byte write-through stores
@@ -816,19 +721,6 @@ static int launch_attn_cfg(const void* qkv, void* out, int B, int N, hipStream_t
     return LDM_OK;
 }
 
-// The shapes the fused form serves: bf16, 256 channels, token counts that take the 16-queries-per-wave instance.
-bool attention_can_fuse_out(int dtype, int B, int N, int C) {
-    return ATTN_FUSE_OUT && dtype == LDM_BF16 && C == 256 && ATTN_STREAM_SMALL && N % 64 == 0 && (long)B * ((N + 127) / 128) < 256 &&
-           !(N % 256 == 0 && N >= 1024 && (long)B * (N / 256) >= 256);
-}
-int launch_attention_fused(const void* qkv, const void* wo_packed, const float* bias, const void* xres, void* out, int B, int N,
-                           int C, hipStream_t stream) {
-    LDM_REQUIRE(qkv && wo_packed && bias && xres && out && B > 0 && N > 0, "bad arguments");
-    LDM_REQUIRE(B <= 65535 && attention_can_fuse_out(LDM_BF16, B, N, C), "shape not served by the fused attention kernel");
-    AttnFuseArgs fa{(const char*)wo_packed, bias, (const char*)xres};
-    return launch_attn_stream<256, 1, 4, AT_WO>(qkv, out, B, N, stream, fa);
-}
-
 // The shapes the folded form serves: bf16 and the token counts that take an instance of the streaming kernel.
 // LDM_ATTN_FOLD=0 (developer switch, read at every call like LDM_DENSE4) keeps the unfolded projections, which gives the
 // parity tests a second GPU implementation of the block to compare with.
@@ -848,7 +740,7 @@ bool attention_can_fold(int dtype, int B, int N, int C) {
 int launch_attention_folded(const void* qv, const void* x, const float* bias, void* out, int B, int N, int C, hipStream_t stream) {
     LDM_REQUIRE(qv && x && bias && out && B > 0 && N > 0, "bad arguments");
     LDM_REQUIRE(attention_can_fold(LDM_BF16, B, N, C), "shape not served by the folded attention kernel");
-    AttnFuseArgs fa{nullptr, bias, (const char*)x};
+    AttnFuseArgs fa{bias, (const char*)x};
     switch (fold_instance(B, N, C)) {
         case 1: return launch_attn_stream<256, 2, 8, AT_FOLD>(qv, out, B, N, stream, fa);
         case 2: return launch_attn_stream<256, 1, 4, AT_FOLD>(qv, out, B, N, stream, fa);

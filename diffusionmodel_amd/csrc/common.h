@@ -153,12 +153,6 @@ const char* tapconv_last_kernel();
 // qkv NHWC-token layout [B, N, 3C] (q | k | v), out [B, N, C]; element type by dtype.
 // ---------------------------------------------------------------------------------------------
 int launch_attention(int dtype, const void* qkv, void* out, int B, int N, int C, hipStream_t stream);
-// The same followed by the output projection and the residual add in one kernel (bf16, C = 256, the shapes
-// attention_can_fuse_out names): out[b,n,:] = softmax-attention(qkv)[b,n,:] Wo + bias + xres[b,n,:].  wo_packed: Wo^T
-// [C][C] bf16, the input channels of every block of 32 permuted (see attention_stream_kernel); bias f32 [C].
-bool attention_can_fuse_out(int dtype, int B, int N, int C);
-int launch_attention_fused(const void* qkv, const void* wo_packed, const float* bias, const void* xres, void* out, int B, int N,
-                           int C, hipStream_t stream);
 // Attention with the projections folded at pack time (see attention_stream_kernel, AT_FOLD): qv = [B, N, 2C] bf16
 // (q' | v'), x = the block's input [B, N, C] (keys and residual), bias = bv Wo + bo (f32 [C]).
 bool attention_can_fold(int dtype, int B, int N, int C);

@@ -229,7 +229,6 @@ struct ResBlockP {
 struct AttnP {
     PackedConv qkv, out;
     int C = 0;
-    void* wo_t = nullptr;   // out.weight transposed [C][C] bf16 in the order of launch_attention_fused (bf16, C = 256 only)
     // bf16, C = 256 / 512: the projections folded (launch_attention_folded): q' | v' as one 1x1 convolution C -> 2C with
     // q' = x (Wq Wk^T) + Wk bq, v' = x (Wv Wo), and the constant bv Wo + bo that joins the residual
     PackedConv qv;
@@ -518,17 +517,6 @@ static int pack_attention(ldm_module* m, const std::string& prefix, int C, AttnP
     so.w = [&](int, int, int co, int ci) { return (*wo)[(size_t)ci * C + co]; };
     so.bias = [&](int co) { return (*bo)[co]; };
     LDM_TRY(pack_conv(so, m->pool, &ap->out, nullptr));
-    if (m->dtype == LDM_BF16 && C == 256) {
-        // row co, position 32 ks + 8 g + j  <-  input channel 32 ks + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
-        std::vector<bf16_t> wt((size_t)C * C);
-        for (int co = 0; co < C; ++co)
-            for (int p = 0; p < C; ++p) {
-                const int ks = p >> 5, g = (p >> 3) & 3, j = p & 7;
-                const int ci = 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
-                wt[(size_t)co * C + p] = host_f2bf((*wo)[(size_t)ci * C + co]);
-            }
-        LDM_TRY(m->pool.upload(&ap->wo_t, wt.data(), wt.size() * 2));
-    }
     if (m->dtype == LDM_BF16 && (C == 256 || C == 512)) {
         // Linear weights are [d_in, d_out].  Composed in double precision:
         //   q_i . k_j = (x_i Wq + bq) . (x_j Wk + bk) = x_i (Wq Wk^T) x_j^T + (Wk bq) . x_j + (terms without j)
@@ -949,8 +937,6 @@ static int run_attention(const AttnP& ap, int dtype, const void* x, void* qkv, v
         return launch_attention_folded(qkv, x, ap.fold_bias, out, B, H * W, ap.C, st);
     }
     LDM_TRY(run_conv(ap.qkv, x, ap.C, nullptr, 0, qkv, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
-    if (ap.wo_t && attention_can_fuse_out(dtype, B, H * W, ap.C))
-        return launch_attention_fused(qkv, ap.wo_t, ap.out.bias, x, out, B, H * W, ap.C, st);
     LDM_TRY(launch_attention(dtype, qkv, att, B, H * W, ap.C, st));
     LDM_TRY(run_conv(ap.out, att, ap.C, nullptr, 0, out, B, H, W, ACT_NONE, x, nullptr, 0, 0, st));
     return LDM_OK;

@@ -132,8 +132,8 @@ def test_resblock_fused_kernel(A, O, B, H):
 @pytest.mark.parametrize("C,B,H,W", [(256, 2, 4, 4), (256, 2, 16, 16), (128, 1, 12, 20), (256, 1, 1, 1), (512, 1, 8, 8),
                                       (256, 64, 16, 16), (256, 64, 32, 32), (512, 64, 16, 32), (256, 64, 8, 8), (256, 9, 8, 16)])
 def test_attention(A, O, dtype, C, B, H, W):
-    # (256, 64, 8, 8), (256, 9, 8, 16): 64 and 128 tokens, bf16: the kernel that also applies the output projection and the
-    #   residual, with fewer key tiles than ring stages (its weight tiles start in the prologue) and a batch that is no multiple of 8
+    # (256, 64, 8, 8), (256, 9, 8, 16): 64 and 128 tokens, bf16: the four-wave streaming kernel with fewer key tiles than
+    #   ring stages and a batch that is no multiple of 8 (bf16 at 256 / 512 channels runs with folded projections)
     # (512, 64, 16, 32): 512 tokens x 256 workgroups of 128 queries: the long-sequence kernel at 512 channels (bf16)
     # (256, 64, 16, 16): enough tokens for the weight-stationary 1x1 kernels of the projections (bf16)
     # (256, 64, 32, 32): 1024 tokens x 256 workgroups of 256 queries: the long-sequence attention kernel (bf16)
