@@ -142,6 +142,14 @@ bool resfuse_shape_ok(int dtype, int C, int B, int H, int W);
 int launch_resfuse(const PackedConv& c1, const PackedConv& c2, const void* x, void* out, int B, int H, int W,
                    const float* tvec, int t_img_stride, int t_step_stride, const int* step_ptr, hipStream_t stream);
 
+// The end of one bf16 DDIM step and the start of the next as one kernel: out_conv on h, the DDIM update of the f32 state
+// (z_in -> z_out, two different buffers) and down1 of the next step on the bf16 rounding of z_out (a1_out).
+// coef [steps][8], ctl = the sampler's control words (step counter at 0, ticket at 4).
+bool ddim_down1_shape_ok(const PackedConv& out_conv, const PackedConv& down1, int B, int H, int W);
+int prepare_ddim_down1();      // sets the kernel's launch attributes on the current device (call outside stream capture)
+int launch_ddim_down1(const PackedConv& out_conv, const PackedConv& down1, const void* h, const float* z_in, float* z_out,
+                      void* a1_out, int B, int H, int W, const float* coef, int* ctl, hipStream_t stream);
+
 int conv_out_hw(int kind, int Hin, int Win, int* Hout, int* Wout);
 int launch_tapconv(const PackedConv& pc, const ConvCall& cc, hipStream_t stream);
 // Name of the kernel the calling thread's last launch_tapconv / launch_upfuse started, spelled as a profiler lists it

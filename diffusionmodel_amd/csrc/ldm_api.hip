@@ -997,6 +997,10 @@ struct DdimFuse {
     void* zl = nullptr;          // bf16 copy of the new state
     const float* coef = nullptr; // [steps][8]
     int* ctl = nullptr;          // {step counter, seed low, seed high, chain0, ticket}
+    // Chained steps (launch_ddim_down1): the update reads z and writes z_next (another buffer), and the same kernel runs
+    // down1 of the NEXT step into the buffer this body's own down1 writes; a body with have_down1 finds it there.
+    float* z_next = nullptr;
+    bool have_down1 = false;
 };
 
 static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, void* eps_out, int B, int H, int W,
@@ -1009,7 +1013,8 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
         if (train) return run_resblock_train(rp, m->dtype, x, tmp, out, b, h, w, t, *train, drop ? train->keep_prob : 1.0f, s2);
         return ::run_resblock(rp, x, tmp, out, b, h, w, t, s2);
     };
-    LDM_TRY(run_conv(m->down1, xin, m->clp, nullptr, 0, ub.a1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
+    if (!(ddim && ddim->have_down1))
+        LDM_TRY(run_conv(m->down1, xin, m->clp, nullptr, 0, ub.a1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_resblock(m->rb[0], ub.a1, ub.b1, ub.s1, B, H, W, tv, st));                 // down_1 = s1
     LDM_TRY(run_conv(m->down2, ub.s1, c1, nullptr, 0, ub.a2, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     LDM_TRY(run_resblock(m->rb[1], ub.a2, ub.b2, ub.s2, B, H2, W2, tv, st));               // down_2 = s2
@@ -1040,6 +1045,8 @@ static int run_unet_body(const ldm_module* m, UnetBufs& ub, const void* xin, voi
         LDM_TRY(run_conv(m->up_conv2, ub.a1, c1, ub.s1, c1, ub.b1, B, H, W, ACT_NONE, nullptr, nullptr, 0, 0, st));
     }
     LDM_TRY(run_resblock(m->rb[6], ub.b1, ub.a1, ub.s1, B, H, W, tv, st));                 // up_res2 -> s1
+    if (ddim && ddim->z_next)
+        return launch_ddim_down1(m->out_conv, m->down1, ub.s1, ddim->z, ddim->z_next, ub.a1, B, H, W, ddim->coef, ddim->ctl, st);
     if (ddim) {
         ConvCall cc;
         cc.in0 = ub.s1; cc.cin0 = c1; cc.out = ddim->zl; cc.B = B; cc.Hin = H; cc.Win = W;
@@ -1148,6 +1155,11 @@ struct ldm_sampler {
     UnetBufs ub;
     float* z = nullptr;       // NHWC f32 state [B,H,W,clp]
     void* zl = nullptr;       // bf16 copy (bf16 mode)
+    // Chained DDIM steps (bf16, the shapes of ddim_down1_shape_ok; LDM_DDIMCHAIN=0 at creation switches them off): step k
+    // reads the state from zbuf[k & 1] and writes zbuf[(k + 1) & 1] in the kernel that also starts step k + 1; the last
+    // step updates its buffer in place.  zbuf[0] = z.
+    float* z2 = nullptr;
+    bool chain_ok = false;
     // One plan per (mode, steps) a caller has asked for: its timestep and coefficient tables in device memory and
     // the graphs captured over them (without / with injected noise).  A plan is built on first use and kept, so a
     // caller that alternates samplers or step counts neither re-uploads nor re-captures anything.
@@ -1183,8 +1195,12 @@ struct ldm_sampler {
     }
 };
 
+static bool sampler_chains(const ldm_sampler* s, int mode, bool tracing) {
+    return s->chain_ok && mode == LDM_DDIM && !tracing;
+}
+
 static int sampler_step(ldm_sampler* s, int mode, bool have_noise, unsigned long long seed, unsigned int chain0,
-                        float* z_trace, float* eps_trace, int k, hipStream_t st) {
+                        float* z_trace, float* eps_trace, int k, int steps, hipStream_t st) {
     ldm_module* m = s->unet;
     const int B = s->B, H = s->H, W = s->W;
     const size_t img = (size_t)B * m->in_ch * H * W;
@@ -1195,6 +1211,14 @@ static int sampler_step(ldm_sampler* s, int mode, bool have_noise, unsigned long
     if (s->dense4) {
         tv.step_stride = m->d4.tv_total;
         LDM_TRY(run_unet_dense4(m, s->ub, xin, s->ub.eps, s->Bp, tv, st));
+    } else if (sampler_chains(s, mode, z_trace || eps_trace)) {
+        // the scheduler update, the step advance and the next step's first convolution happen in one kernel
+        float* zb[2] = {s->z, s->z2};
+        DdimFuse f;
+        f.z = zb[k & 1]; f.zl = s->zl; f.coef = s->coef; f.ctl = s->step;
+        f.z_next = k + 1 < steps ? zb[(k + 1) & 1] : nullptr;
+        f.have_down1 = k > 0;
+        return run_unet_body(m, s->ub, xin, nullptr, B, H, W, tv, st, &f);
     } else if (mode == LDM_DDIM && !eps_trace && m->clp == 64 && tapconv_can_fuse_ddim(m->out_conv, B, H, W)) {
         // the scheduler update and the step advance happen in the epilogue of the last convolution
         DdimFuse f;
@@ -1603,6 +1627,14 @@ int ldm_sampler_create(ldm_sampler** out, ldm_module* unet, int num_time, int ba
     if (unet->dtype == LDM_BF16) {
         LDM_TRY(s->pool.alloc(&s->zl, nz * 2));
         LDM_HIP(hipMemset(s->zl, 0, nz * 2));
+        const char* e = getenv("LDM_DDIMCHAIN");
+        s->chain_ok = !(e && e[0] == '0') && !s->dense4 && unet->clp == 64 && tapconv_can_fuse_ddim(unet->out_conv, batch, H, W) &&
+                      ddim_down1_shape_ok(unet->out_conv, unet->down1, batch, H, W);
+        if (s->chain_ok) {
+            LDM_TRY(prepare_ddim_down1());
+            LDM_TRY(s->pool.alloc((void**)&s->z2, nz * 4));
+            LDM_HIP(hipMemset(s->z2, 0, nz * 4));
+        }
     }
     LDM_TRY(s->pool.alloc((void**)&s->step, 32));
     LDM_HIP(hipMemset(s->step, 0, 32));
@@ -1718,7 +1750,7 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
             LDM_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = LDM_OK;
             for (int k = 0; k < steps && rc == LDM_OK; ++k)
-                rc = sampler_step(s, mode, have_noise, seed, chain0, nullptr, nullptr, k, s->cap_stream);
+                rc = sampler_step(s, mode, have_noise, seed, chain0, nullptr, nullptr, k, steps, s->cap_stream);
             hipError_t e = hipStreamEndCapture(s->cap_stream, &graph);
             if (rc != LDM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LDM_HIP(e);
@@ -1729,9 +1761,11 @@ int ldm_sampler_run(ldm_sampler* s, int mode, int ddim_steps, const float* z0, c
         }
         LDM_HIP(hipGraphLaunch(exec, st));
     } else {
-        for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, mode, have_noise, seed, chain0, z_trace, eps_trace, k, st));
+        for (int k = 0; k < steps; ++k) LDM_TRY(sampler_step(s, mode, have_noise, seed, chain0, z_trace, eps_trace, k, steps, st));
     }
-    LDM_TRY(launch_nhwc_to_nchw(s->z, LDM_F32, z_out, B, m->in_ch, m->clp, H, W, st));
+    // (chained steps leave the final state in the buffer of the last step's parity)
+    const float* z_final = sampler_chains(s, mode, tracing) && ((steps - 1) & 1) ? s->z2 : s->z;
+    LDM_TRY(launch_nhwc_to_nchw(z_final, LDM_F32, z_out, B, m->in_ch, m->clp, H, W, st));
     return LDM_OK;
 }
 

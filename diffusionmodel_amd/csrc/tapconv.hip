@@ -93,6 +93,7 @@ struct TapConvArgs {
     int t_img_stride, t_step_stride, t_pix_stride;
     long w_phase_stride;         // bytes
     float* sched_z;              // fused DDIM update: f32 sampler state (in place), else null
+    float* sched_z_out;          // DDIM update + next step's first convolution as one kernel: the new state (sched_z is only read)
     const float* sched_coef;     // its coefficient table [steps][8]
     int* sched_ticket;           // optional: workgroup counter; the last workgroup advances *step_ptr
     const char* w2;              // fused ResidualBlock: packed weights and bias of the second convolution
@@ -1054,11 +1055,28 @@ constexpr int RF_RINGB = 4 * RF_PLANE;
 constexpr int RF_NPROD = RF_R / 2 + 1;                  // producer steps (18 rows of y)
 constexpr int RF_LAG = 3;                               // consumers run this many steps behind
 constexpr int RF_NS = RF_R / 2 + RF_LAG;                // steps of a workgroup
-constexpr int RF_BIAS = 2 * RF_RINGB + 8 * 1024 + 8 * 1024;  // two rings, a 1-KiB dump area per wave, 2 KiB of residual staging per consumer wave
-constexpr int RF_LDS = RF_BIAS + 8 * 128;               // and 128 bytes per wave: the bias of its 32 output channels
+// two rings, a 1-KiB dump area per wave, the staging rows of the epilogue inputs (RF_RES: 2 KiB of residual per consumer
+// wave; RF_DDIM: 4 KiB of sampler state per producer wave), and 128 bytes per wave: the bias of its 32 output channels
+constexpr int rf_bias_off(int rm) { return 2 * RF_RINGB + 8 * 1024 + (rm == 0 ? 8 : 16) * 1024; }
+constexpr int rf_lds(int rm) { return rf_bias_off(rm) + 8 * 128; }
 
+// RM: what the two chained convolutions are.
+//   RF_RES   the ResidualBlock described above.
+//   RF_DDIM  the end of one sampler step and the start of the next (bf16 DDIM sampling, src/main.rs:486-492, :499, :525):
+//            producers run out_conv and the DDIM update of the f32 state (as tapconv_ws64_kernel<WS_DDIM>: the predicted
+//            noise never goes to memory; state rows are staged through LDS and read from a.sched_z, the new state goes to
+//            a.sched_z_out - two buffers, because the rim rows of a band are recomputed by its neighbours and must see
+//            the old state), the bf16 copy of the new state goes into the y ring only, and consumers run down1 of the
+//            NEXT step on it (plain epilogue).  The bf16 copy is never written to memory and one launch is saved.
+enum { RF_RES = 0, RF_DDIM = 1 };
+template <int RM>
 __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) {
     constexpr int NF = 2, KS = 18, HR = 2, XD = 3;
+    constexpr bool DDIM = RM == RF_DDIM;
+    constexpr int RF_BIAS = rf_bias_off(RM);
+    // staged epilogue inputs per half (1-KiB pieces) and stores per epilogue row, by role
+    constexpr int STG_P = DDIM ? 2 * HR : 0, STG_C = DDIM ? 0 : HR;
+    constexpr int NSTO_P = DDIM ? 2 : 0, NSTO_C = 1;
 #ifdef TAPCONV_STAMP
     // diagnostic builds: 100-MHz real-time stamps of wave 0 (producer) and wave 4 (consumer), 16 slots each: start,
     // prologue done, end of every step, end (tools/rflife.py prints them)
@@ -1079,8 +1097,9 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
     char* const xring = smem;
     char* const yring = smem + RF_RINGB;
     char* const dump = smem + 2 * RF_RINGB + wave * 1024;
-    // consumers: the residual rows of the half whose epilogue is pending, 1 KiB per row (16 bytes per lane)
-    char* const stage = smem + 2 * RF_RINGB + 8 * 1024 + (wave & 3) * 2048;
+    // the staged rows of the half whose epilogue is pending, 1 KiB per piece (16 bytes per lane): the residual rows of a
+    // consumer (RF_RES), the state rows of a producer as two pieces each (RF_DDIM)
+    char* const stage = smem + 2 * RF_RINGB + 8 * 1024 + (wave & 3) * (DDIM ? 4096 : 2048);
 
     // the zero pixel of both rings (read by lanes whose pixel lies beside the image)
     if (tid < 16) {
@@ -1092,11 +1111,17 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
     // pieces (4 planes x 2 rows x 2 halves of a row) are issued by the 8 waves, two each: piece e = wave * 2 + i.
     const size_t img_base = (size_t)img * a.Hin * 64;
     auto issue_piece = [&](int q, int i, bool live) {
+        // (RF_DDIM consumers: an opaque copy of the lane index, so that the lane's part of the address is formed here and
+        // not once in front of both roles, where it is then spilled across the producers' loop)
+        int ln = lane;
+        if constexpr (DDIM) {
+            if (consumer) asm volatile("" : "+v"(ln));
+        }
         const int e = wave * 2 + i;
-        const int plane = e >> 2, rr = (e >> 1) & 1, hx = (e & 1) * 32 + (lane >> 1);
+        const int plane = e >> 2, rr = (e >> 1) & 1, hx = (e & 1) * 32 + (ln >> 1);
         const int iy = y0 + 2 * q - 2 + rr;
         const bool ok = live && (unsigned)iy < (unsigned)a.Hin;
-        const char* src = ok ? a.in0 + (img_base + (size_t)iy * 64 + hx) * 128 + plane * 32 + (lane & 1) * 16 : zero;
+        const char* src = ok ? a.in0 + (img_base + (size_t)iy * 64 + hx) * 128 + plane * 32 + (ln & 1) * 16 : zero;
         char* dst = live ? xring + plane * RF_PLANE + (((2 * q) & 7) + rr) * RF_ROWB + (e & 1) * 1024 : dump;
         glds16(src, dst);
     };
@@ -1130,8 +1155,22 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
     const int step = a.step_ptr ? *a.step_ptr : 0;
     // ld: the residual rows of the half whose epilogue is pending (consumers), or the block's time vector of this
     // lane's eight channels (producers)
-    u32x4 ld[HR] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-    if (!consumer) {
+    u32x4 ld[DDIM ? 2 * HR : HR];
+#pragma unroll
+    for (int i = 0; i < (DDIM ? 2 * HR : HR); ++i) ld[i] = u32x4{0u, 0u, 0u, 0u};
+    float k_s1m = 0.f, k_rsa = 0.f, k_c1 = 0.f, k_c2 = 0.f;
+    if constexpr (DDIM) {
+        if (!consumer) {
+            const float* cf = a.sched_coef + (size_t)step * 8;
+            const bool last = cf[6] != 0.f;
+            // (wave-uniform values: kept in scalar registers, this mode has no vector register to spare)
+            auto uni = [](float f) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f))); };
+            k_s1m = uni(cf[1]);
+            k_rsa = uni(1.0f / cf[0]);
+            k_c1 = uni(last ? 1.0f : cf[2]);
+            k_c2 = uni(last ? 0.0f : cf[3]);
+        }
+    } else if (!consumer) {
         const float* tp = a.tvec + (size_t)img * a.t_img_stride + (size_t)step * a.t_step_stride + co;
         ld[0] = *(const u32x4*)tp;
         ld[1] = *(const u32x4*)(tp + 4);
@@ -1163,7 +1202,7 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
                 v0[q] = u2f(sw[0]);
                 v1[q] = u2f(sw[1]);
             }
-            if (CONS) {
+            if (CONS && !DDIM) {
                 const unsigned int u0 = ld[j][0], u1 = ld[j][1], u2 = ld[j][2], u3 = ld[j][3];
                 v0[0] += bf2f((bf16_t)(u0 & 0xffffu)); v0[1] += bf2f((bf16_t)(u0 >> 16));
                 v0[2] += bf2f((bf16_t)(u1 & 0xffffu)); v0[3] += bf2f((bf16_t)(u1 >> 16));
@@ -1171,24 +1210,49 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
                 v1[2] += bf2f((bf16_t)(u3 & 0xffffu)); v1[3] += bf2f((bf16_t)(u3 >> 16));
             }
         } else if (s < 8) {
-            if (s == 1) { v0[0] = silu_f<false>(v0[0]); v0[1] = silu_f<false>(v0[1]); }
-            if (s == 2) v0[2] = silu_f<false>(v0[2]);
-            if (s == 3) v0[3] = silu_f<false>(v0[3]);
-            if (s == 4) v1[0] = silu_f<false>(v1[0]);
-            if (s == 5) v1[1] = silu_f<false>(v1[1]);
-            if (s == 6) v1[2] = silu_f<false>(v1[2]);
-            if (s == 7) v1[3] = silu_f<false>(v1[3]);
+            if constexpr (!DDIM) {
+                if (s == 1) { v0[0] = silu_f<false>(v0[0]); v0[1] = silu_f<false>(v0[1]); }
+                if (s == 2) v0[2] = silu_f<false>(v0[2]);
+                if (s == 3) v0[3] = silu_f<false>(v0[3]);
+                if (s == 4) v1[0] = silu_f<false>(v1[0]);
+                if (s == 5) v1[1] = silu_f<false>(v1[1]);
+                if (s == 6) v1[2] = silu_f<false>(v1[2]);
+                if (s == 7) v1[3] = silu_f<false>(v1[3]);
+            }
         } else {
             const int row = rowP + j;                      // band relative
             if (!CONS) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned int t0 = ld[0][q], t1 = ld[1][q];
-                    v0[q] += u2f(t0);
-                    v1[q] += u2f(t1);
-                }
                 // y rows above / below the image are the zero padding of conv2
                 const bool inside = (unsigned)(y0 + row) < (unsigned)a.Hin;
+                if constexpr (DDIM) {
+                    // v = predicted noise; the update of tapconv_ws64_kernel<WS_DDIM>, operation for operation
+                    f32x4 z0, z1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        z0[q] = u2f(ld[2 * j][q]);
+                        z1[q] = u2f(ld[2 * j + 1][q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        z0[q] = ((z0[q] - v0[q] * k_s1m) * k_rsa) * k_c1 + v0[q] * k_c2;
+                        z1[q] = ((z1[q] - v1[q] * k_s1m) * k_rsa) * k_c1 + v1[q] * k_c2;
+                    }
+                    // the band's own rows go to the new state; the rim rows belong to the neighbouring bands
+                    if ((unsigned)row < (unsigned)RF_R) {
+                        float* zo = a.sched_z_out + out_base + ((size_t)row * 64 + colP) * 64;
+                        *(f32x4*)zo = z0;
+                        *(f32x4*)(zo + 4) = z1;
+                    }
+                    v0 = z0;
+                    v1 = z1;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int t0 = ld[0][q], t1 = ld[1][q];
+                        v0[q] += u2f(t0);
+                        v1[q] += u2f(t1);
+                    }
+                }
                 u32x4 o;
                 o[0] = inside ? pack2(v0[0], v0[1]) : 0u;
                 o[1] = inside ? pack2(v0[2], v0[3]) : 0u;
@@ -1221,11 +1285,19 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         // Vector-memory operations of a consumer half, in issue order: the DMA piece (f = 0), the residual row 0
         // (f = 1), the store of the pending epilogue's row 0 (f = 10), the residual row 1 (f = 13), the store of row 1
         // (f = 22).  Row 0 of the PREVIOUS half's residual is used at f = 0: three younger operations may still fly.
-        if (EPI && CONS) {
+        // RF_DDIM, producer half: the DMA piece (f = 0), the four state pieces (f = 1 .. 4), the two stores of the pending
+        // epilogue's row 0 (f = 10) and of its row 1 (f = 22).  The state pieces of the previous half are read here; what
+        // that half issued behind them are the stores of the half before IT, and a counted wait must not allow more
+        // operations in flight than were issued: the stores of a rim row are not issued, so the halves of step 0 (rows
+        // -1 and 0) leave two stores behind the state pieces of the next half, not four - they are waited for at the
+        // top of the halves of step 1 (r0 = 1).
+        constexpr int STG = CONS ? STG_C : STG_P;
+        if (EPI && STG > 0) {
             if (drain) wait_vmcnt<0>();
-            else wait_vmcnt<1>();
+            else if (DDIM && r0 == 1) wait_vmcnt<NSTO_P>();
+            else wait_vmcnt<DDIM ? 2 * NSTO_P : 1>();
 #pragma unroll
-            for (int i = 0; i < HR; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+            for (int i = 0; i < STG; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
         }
         f32x4 acc[NF][HR];
 #pragma unroll
@@ -1237,9 +1309,13 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         bool edge[3];
 #pragma unroll
         for (int h = 0; h < HR + 2; ++h) rowb[h] = ((jb + h) & 7) * RF_ROWB + lane_po;
+        // (RF_DDIM consumers: an opaque copy, so that what depends on the column is computed here and not once in front
+        // of both roles, where it is then spilled across the producers' loop)
+        int lx = l15;
+        if constexpr (CONS && DDIM) asm volatile("" : "+v"(lx));
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int px = c0 + l15 + dx - 1;
+            const int px = c0 + lx + dx - 1;
             edge[dx] = (unsigned)px > 63u;
             pxo[dx] = (unsigned)px * 32u;
         }
@@ -1257,14 +1333,23 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         for (int f = 0; f < NFR; ++f) {
             if (f + XD - 1 < NFR) xf[(f + XD - 1) % XD] = *fr(f + XD - 1);
             // memory work, one operation per fragment step: the DMA piece, then (consumers) the residual rows
-            if (f == (CONS ? 2 : 0)) issue_piece(piece_q, HALF, piece_live);
+            if (f == (CONS && !DDIM ? 2 : 0)) issue_piece(piece_q, HALF, piece_live);
             if (EPI && f % 4 != 3) epi_slice(role_tag, slice);
             if (f % 4 != 3) ++slice;
-            if (CONS && f < 2) {
+            if (CONS && !DDIM && f < 2) {
                 // this half's residual row f into its staging row, which was read back at the top
                 const int i = f;
                 asm volatile("" ::: "memory");
                 glds16(a.in0 + (out_base + ((size_t)(r0 + i) * 64 + c0) * 64) * 2, stage + i * 1024);
+                asm volatile("" ::: "memory");
+            }
+            if (!CONS && DDIM && f >= 1 && f <= 4) {
+                // the state of this half's row (f - 1) / 2, channels co + 4 ((f - 1) & 1) .. + 3, into its staging piece; a
+                // row outside the image (its y row is zero padding) reads the zero page
+                const int i = f - 1, row = r0 + (i >> 1);
+                const bool ok = (unsigned)(y0 + row) < (unsigned)a.Hin;
+                asm volatile("" ::: "memory");
+                glds16(ok ? (const char*)(a.sched_z + out_base + ((long)row * 64 + c0) * 64 + (i & 1) * 4) : zero, stage + i * 1024);
                 asm volatile("" ::: "memory");
             }
             const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
@@ -1292,10 +1377,11 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
         colP = c0;
     };
     auto flush_epilogue = [&](auto role_tag) {      // the epilogue of the last half of a role
-        if (decltype(role_tag)::value) {
+        constexpr int STG = decltype(role_tag)::value ? STG_C : STG_P;
+        if (STG > 0) {
             wait_vmcnt<0>();
 #pragma unroll
-            for (int i = 0; i < HR; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
+            for (int i = 0; i < STG; ++i) ld[i] = *(const u32x4*)(stage + i * 1024 + lane * 16);
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) epi_slice(role_tag, s);
@@ -1305,7 +1391,9 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
     // the y rows written in this step are in LDS, and every wave is done with the rows the next step overwrites
     auto step_end = [&](int in_flight) {
         // in_flight: how many of this wave's youngest operations, all issued in this step, may still fly
-        if (in_flight >= 8) wait_vmcnt<8>();
+        if (in_flight >= 10) wait_vmcnt<10>();
+        else if (in_flight >= 8) wait_vmcnt<8>();
+        else if (in_flight >= 6) wait_vmcnt<6>();
         else wait_vmcnt<2>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1346,9 +1434,12 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
             else do_half(role_tag, BoolC<false>{}, BoolC<true>{}, ring, jb, r0, c_first, pq, plive, false);
             do_half(role_tag, BoolC<true>{}, BoolC<true>{}, ring, jb, r0, c_first + 16, pq, plive, !pending);
             pending = true;
-            // a consumer step issues ten operations (per half: two residual rows, the piece, two stores); the
-            // youngest eight start with the first half's piece
-            step_end(CONS && k > RF_LAG ? 8 : 2);
+            // RF_RES: a consumer step issues ten operations (per half: two residual rows, the piece, two stores); the
+            // youngest eight start with the first half's piece.  RF_DDIM: a consumer step behind its first issues six
+            // (per half the piece and two stores), a producer step at least ten (per half the piece and four state
+            // pieces, then up to four stores).
+            if constexpr (DDIM) step_end(CONS ? (k > RF_LAG ? 6 : 2) : 10);
+            else step_end(CONS && k > RF_LAG ? 8 : 2);
             RF_STAMP(2 + k);
         }
         if (pending) flush_epilogue(role_tag);
@@ -1357,6 +1448,19 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
     else run(BoolC<false>{});
     RF_STAMP(2 + RF_NS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (DDIM && a.sched_ticket) {
+        // advance the sampler's step counter once per launch (see tapconv_ws64_kernel): every wave read the counter at
+        // its start, and a workgroup draws its ticket when all its waves are here
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(a.sched_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (int)gridDim.x - 1) {
+                __hip_atomic_store(a.sched_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(const_cast<int*>(a.step_ptr), step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2561,9 +2665,39 @@ int launch_resfuse(const PackedConv& c1, const PackedConv& c2, const void* x, vo
     if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
     static bool lds_set[kMaxDevices] = {};
-    LDM_TRY(allow_dynamic_lds((const void*)resfuse64_kernel, 160 * 1024, lds_set));
-    g_last_kernel = "ldm::resfuse64_kernel(ldm::TapConvArgs)";
-    hipLaunchKernelGGL(resfuse64_kernel, dim3((unsigned)(B * (H / RF_R))), dim3(512), RF_LDS, stream, a);
+    LDM_TRY(allow_dynamic_lds((const void*)resfuse64_kernel<RF_RES>, 160 * 1024, lds_set));
+    g_last_kernel = "void ldm::resfuse64_kernel<0>(ldm::TapConvArgs)";
+    hipLaunchKernelGGL(resfuse64_kernel<RF_RES>, dim3((unsigned)(B * (H / RF_R))), dim3(512), rf_lds(RF_RES), stream, a);
+    LDM_HIP(hipGetLastError());
+    return LDM_OK;
+}
+
+// The end of one bf16 DDIM step and the start of the next as one kernel (resfuse64_kernel<RF_DDIM>): out_conv on h, the
+// DDIM update z_out = update(z_in, predicted noise) in f32, and down1 of the next step on the bf16 rounding of z_out,
+// which never goes to memory.  z_in and z_out must be different buffers.  The shapes are those of the fused
+// ResidualBlock; ctl = {step counter, ..., ticket at ctl[4]} as for the fused DDIM convolution.
+bool ddim_down1_shape_ok(const PackedConv& out_conv, const PackedConv& down1, int B, int H, int W) {
+    return out_conv.kind == CONV3x3_S1 && down1.kind == CONV3x3_S1 && out_conv.dtype == LDM_BF16 && down1.dtype == LDM_BF16 &&
+           out_conv.cin == 64 && out_conv.cout == 64 && down1.cin == 64 && down1.cout == 64 && resfuse_shape_ok(LDM_BF16, 64, B, H, W);
+}
+// The kernel's launch attribute (160 KiB of dynamic LDS), set on the current device outside any stream capture.
+static bool g_ddim_down1_lds_set[kMaxDevices] = {};
+int prepare_ddim_down1() { return allow_dynamic_lds((const void*)resfuse64_kernel<RF_DDIM>, 160 * 1024, g_ddim_down1_lds_set); }
+int launch_ddim_down1(const PackedConv& out_conv, const PackedConv& down1, const void* h, const float* z_in, float* z_out,
+                      void* a1_out, int B, int H, int W, const float* coef, int* ctl, hipStream_t stream) {
+    LDM_REQUIRE(h && z_in && z_out && a1_out && coef && ctl && z_in != z_out && h != a1_out, "null or aliased tensor");
+    LDM_REQUIRE(out_conv.w && out_conv.bias && down1.w && down1.bias && ddim_down1_shape_ok(out_conv, down1, B, H, W),
+                "shape not served by the fused DDIM / down1 kernel");
+    TapConvArgs a{};
+    a.in0 = (const char*)h; a.out = (char*)a1_out;
+    a.w = (const char*)out_conv.w; a.bias = out_conv.bias;
+    a.w2 = (const char*)down1.w; a.bias2 = down1.bias;
+    a.sched_z = const_cast<float*>(z_in); a.sched_z_out = z_out; a.sched_coef = coef;
+    a.step_ptr = ctl; a.sched_ticket = ctl + 4;
+    a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.cout = 64;
+    LDM_TRY(prepare_ddim_down1());
+    g_last_kernel = "void ldm::resfuse64_kernel<1>(ldm::TapConvArgs)";
+    hipLaunchKernelGGL(resfuse64_kernel<RF_DDIM>, dim3((unsigned)(B * (H / RF_R))), dim3(512), rf_lds(RF_DDIM), stream, a);
     LDM_HIP(hipGetLastError());
     return LDM_OK;
 }

@@ -304,6 +304,40 @@ def test_full_size_chain_is_deterministic(A):
     assert torch.equal(eager, ref) and torch.equal(other, ref)
 
 
+@pytest.mark.parametrize("B,S,steps", [(32, 64, 5), (64, 64, 4), (16, 128, 3)])
+def test_chained_ddim_steps_equal_the_single_step_kernels(A, B, S, steps):
+    """bf16 DDIM on 64-pixel-wide latents with at least 128 bands of 16 rows: out_conv, the DDIM update and the NEXT
+    step's down1 run as one kernel (the bf16 copy of the state stays in LDS, the f32 state alternates between two
+    buffers).  A sampler created under LDM_DDIMCHAIN=0 runs the same steps as out_conv + update and down1: the same
+    arithmetic in the same order, so the final latents must be equal bit for bit - with an odd and an even number of
+    steps (the final state ends in either buffer), eagerly and as a graph."""
+    w = A.make_synthetic_weights(A.LDMConfig(), 0)
+    z0 = torch.randn(B, 64, S, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    _say(f"chained ddim steps B={B} H={S} steps={steps}")
+    old = os.environ.get("LDM_DDIMCHAIN")
+    try:
+        os.environ["LDM_DDIMCHAIN"] = "0"
+        m0 = A.DiffusionModel(64, 3, 1000, 256, dtype="bf16", weights=w)
+        plain = m0.ddim_sample(B, steps, spatial=(S, 64), z0=z0, use_graph=False)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("LDM_DDIMCHAIN", None)
+        else:
+            os.environ["LDM_DDIMCHAIN"] = old
+    m1 = A.DiffusionModel(64, 3, 1000, 256, dtype="bf16", weights=w)
+    eager = m1.ddim_sample(B, steps, spatial=(S, 64), z0=z0, use_graph=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(plain).all()
+    d = (eager - plain).abs().max().item()
+    _say(f"  max |chained - single| = {d:.3e}")
+    assert torch.equal(eager, plain)
+    for _ in range(2):
+        graph = m1.ddim_sample(B, steps, spatial=(S, 64), z0=z0, use_graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(graph, plain)
+
+
 @pytest.mark.parametrize("dtype,B,scaled", [("fp32", 4, False), ("fp32", 20, False), ("bf16", 20, False),
                                             ("bf16", 64, False), ("fp32", 3, True), ("bf16", 16, True)])
 def test_whole_image_matrices_at_4x4_match_the_tap_kernels(A, O, dtype, B, scaled):
