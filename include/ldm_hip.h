@@ -30,6 +30,8 @@
  *                          in f32, 0 in bf16); read once per process.
  *   LDM_RESFUSE=0          run a ResidualBlock of the 64-channel level as its two convolution launches instead of the
  *                          one fused kernel (same bits; comparison runs and tests); read once per process.
+ *   LDM_DDIMCHAIN=0        bf16 DDIM sampling: keep out_conv + DDIM update and the next step's down1 as two launches instead
+ *                          of the one chained kernel (same bits; comparison runs and tests); read by ldm_sampler_create.
  *   LDM_ATTN_FOLD=0        run the bf16 Attention block (256 / 512 channels) with the reference's four Linears instead of
  *                          the projections folded at pack time (same mathematics, other roundings; comparison runs and
  *                          tests); read at every call (a captured sampler graph keeps the choice made at capture).
