@@ -18,4 +18,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     run l1 $ctr tools/convone.py conv3x3 64 64 64 64
     run sched $ctr tools/schedone.py 64 64 64
     run rf $ctr tools/resone.py 64
+    run ch $ctr tools/chainone.py 64 12
 done

@@ -9,8 +9,11 @@ SHAPES = {"l3": ("3x3 256->256 on [64,16,16,256] bf16", 2 * 64 * 16 * 16 * 256 *
           "sched": ("[64,64,64,64] f32 ddpm", 16 * 64 * 64 * 64 * 64),
           # the fused ResidualBlock: x in, block output out, two weight sets (its forward also converts NCHW <-> NHWC
           # around the kernel; only the kernel's own launches are averaged)
-          "rf": ("ResidualBlock 64 channels on [64,64,64,64] bf16", 2 * 64 * 64 * 64 * 64 * 2 + 2 * 64 * 64 * 9 * 2)}
-WANT = {"l3": "tapconv", "l2": "tapconv", "l1": "tapconv", "sched": "sched_step_kernel", "rf": "resfuse64_kernel"}
+          "rf": ("ResidualBlock 64 channels on [64,64,64,64] bf16", 2 * 64 * 64 * 64 * 64 * 2 + 2 * 64 * 64 * 9 * 2),
+          # the chained DDIM step: h in, f32 state in and out, down1's output out, two weight sets
+          "ch": ("out_conv + DDIM update + down1 on [64,64,64,64] bf16", 64 * 64 * 64 * 64 * (2 + 4 + 4 + 2) + 2 * 64 * 64 * 9 * 2)}
+WANT = {"l3": "tapconv", "l2": "tapconv", "l1": "tapconv", "sched": "sched_step_kernel", "rf": "resfuse64_kernel<0>",
+        "ch": "resfuse64_kernel<1>"}
 def avg(name, ctr):
     files = glob.glob(os.path.join(src, f"{name}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
     assert files, (name, ctr)
