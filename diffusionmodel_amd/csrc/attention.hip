@@ -331,7 +331,7 @@ static __device__ unsigned long long* g_attn_rt = nullptr;
 #else
 #define AT_STAMP(k_) do { } while (0)
 #endif
-struct AttnFuseArgs {      // AT_FOLD: the constant vector (f32 [D]) and the block's input (keys, residual)
+struct AttnFoldArgs {      // AT_FOLD: the constant vector (f32 [D]) and the block's input (keys, residual)
     const float* bias;
     const char* xres;
 };
@@ -345,7 +345,7 @@ struct AttnFuseArgs {      // AT_FOLD: the constant vector (f32 [D]) and the blo
 enum { AT_PLAIN = 0, AT_FOLD = 1 };
 template <int D, int QF, int NW, int MODE = AT_PLAIN>
 __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
-                                                                  int N, float scale_log2e, int B, AttnFuseArgs fa) {
+                                                                  int N, float scale_log2e, int B, AttnFoldArgs fa) {
     constexpr bool FOLD = MODE == AT_FOLD;
     constexpr int RB = D * 2, KT = 32, KF = 2, KS = RB / 64, DF = D / 16;
     // row strides of the query, key and value matrices
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attention_stream_kernel(const char
 }
 
 template <int D, int QF, int NW, int MODE = AT_PLAIN>
-static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream, AttnFuseArgs fa = AttnFuseArgs{}) {
+static int launch_attn_stream(const void* qkv, void* out, int B, int N, hipStream_t stream, AttnFoldArgs fa = AttnFoldArgs{}) {
     constexpr int QB = NW * QF * 16;
     constexpr size_t stage = (size_t)2 * 32 * D * 2;
     constexpr size_t lds = (4 * stage <= 160 * 1024 ? 4 : 2) * stage + (MODE != AT_PLAIN ? 2048 : 0);
@@ -740,7 +740,7 @@ bool attention_can_fold(int dtype, int B, int N, int C) {
 int launch_attention_folded(const void* qv, const void* x, const float* bias, void* out, int B, int N, int C, hipStream_t stream) {
     LDM_REQUIRE(qv && x && bias && out && B > 0 && N > 0, "bad arguments");
     LDM_REQUIRE(attention_can_fold(LDM_BF16, B, N, C), "shape not served by the folded attention kernel");
-    AttnFuseArgs fa{bias, (const char*)x};
+    AttnFoldArgs fa{bias, (const char*)x};
     switch (fold_instance(B, N, C)) {
         case 1: return launch_attn_stream<256, 2, 8, AT_FOLD>(qv, out, B, N, stream, fa);
         case 2: return launch_attn_stream<256, 1, 4, AT_FOLD>(qv, out, B, N, stream, fa);
