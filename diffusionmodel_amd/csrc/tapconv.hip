@@ -133,6 +133,21 @@ struct TapConvArgs {
 #endif
 
 
+#ifdef TAPCONV_STAMP
+// diagnostic builds: the stamp buffer LDM_DBG_RT_PTR names, for the kernel family LDM_DBG_RT_ONLY names (all when unset)
+static unsigned long long* dbg_rt_for(const char* who) {
+    const char* e = getenv("LDM_DBG_RT_PTR");
+    const char* only = getenv("LDM_DBG_RT_ONLY");
+    if (!e) return nullptr;
+    if (only) {
+        int i = 0;
+        while (only[i] && only[i] == who[i]) ++i;
+        if (only[i] != who[i]) return nullptr;
+    }
+    return (unsigned long long*)strtoull(e, nullptr, 16);
+}
+#endif
+
 // SiLU.  f32 mode divides exactly; bf16 mode multiplies by the hardware reciprocal (1 ulp of f32, far
 // below the bf16 rounding of the result): the IEEE division costs about as many issue cycles per
 // output element as all the MFMAs that produced it at the 64-channel level.
@@ -159,6 +174,11 @@ __device__ __forceinline__ unsigned int f2u(float f) { return __builtin_bit_cast
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// the same with the non-temporal cache policy (nt): data that is read once and not again soon
+__device__ __forceinline__ void glds16_nt(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
 }
 
 // Output stores of the convolution kernels are write-through (sc1): the bytes go to memory as the kernel runs and the
@@ -1240,8 +1260,12 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
                     // the band's own rows go to the new state; the rim rows belong to the neighbouring bands
                     if ((unsigned)row < (unsigned)RF_R) {
                         float* zo = a.sched_z_out + out_base + ((size_t)row * 64 + colP) * 64;
-                        *(f32x4*)zo = z0;
-                        *(f32x4*)(zo + 4) = z1;
+                        // The state is a stream: 67 MB read and 67 MB written per step, each byte touched once, next
+                        // to activations that the following kernels read again within microseconds.  Loaded and stored
+                        // non-temporally it stops displacing them from the memory-side cache: this kernel is no
+                        // faster (54.6 -> 56.1 us), every other kernel of the step is (+3.2 % on the 50-step benchmark).
+                        __builtin_nontemporal_store(z0, (f32x4*)zo);
+                        __builtin_nontemporal_store(z1, (f32x4*)(zo + 4));
                     }
                     v0 = z0;
                     v1 = z1;
@@ -1349,7 +1373,7 @@ __global__ __launch_bounds__(512, 2) void resfuse64_kernel(const TapConvArgs a) 
                 const int i = f - 1, row = r0 + (i >> 1);
                 const bool ok = (unsigned)(y0 + row) < (unsigned)a.Hin;
                 asm volatile("" ::: "memory");
-                glds16(ok ? (const char*)(a.sched_z + out_base + ((long)row * 64 + c0) * 64 + (i & 1) * 4) : zero, stage + i * 1024);
+                glds16_nt(ok ? (const char*)(a.sched_z + out_base + ((long)row * 64 + c0) * 64 + (i & 1) * 4) : zero, stage + i * 1024);
                 asm volatile("" ::: "memory");
             }
             const int h = f / 6, dx = (f % 6) >> 1, kk = f & 1;
@@ -2354,7 +2378,7 @@ static int launch_cfg(TapConvArgs& a, int nphase, hipStream_t stream) {
     a.dbg = nullptr;
     if (const char* e = getenv("LDM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 16);
     a.dbg_rt = nullptr;
-    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+    a.dbg_rt = dbg_rt_for("tiled");
 #endif
     static_assert((size_t)TH * 16 * (BN * 4 + 16) <= 160 * 1024, "epilogue staging exceeds LDS");
     a.tiles_x = (a.Wg + 15) / 16;
@@ -2397,7 +2421,7 @@ static int launch_ws64(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
     a.dbg = nullptr;
     a.dbg_rt = nullptr;
-    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+    a.dbg_rt = dbg_rt_for("ws64");
 #endif
     int ncu = 0;
     LDM_TRY(device_cu_count(&ncu));
@@ -2440,7 +2464,7 @@ static int launch_s2ws(TapConvArgs& a, hipStream_t stream) {
 #ifdef TAPCONV_STAMP
     a.dbg = nullptr;
     a.dbg_rt = nullptr;
-    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+    a.dbg_rt = dbg_rt_for("s2ws");
 #endif
     int ncu = 0;
     LDM_TRY(device_cu_count(&ncu));
@@ -2662,7 +2686,7 @@ int launch_resfuse(const PackedConv& c1, const PackedConv& c2, const void* x, vo
     a.tvec = tvec; a.t_img_stride = t_img_stride; a.t_step_stride = t_step_stride; a.step_ptr = step_ptr;
     a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.cout = 64;
 #ifdef TAPCONV_STAMP
-    if (const char* e = getenv("LDM_DBG_RT_PTR")) a.dbg_rt = (unsigned long long*)strtoull(e, nullptr, 16);
+    a.dbg_rt = dbg_rt_for("resfuse");
 #endif
     static bool lds_set[kMaxDevices] = {};
     LDM_TRY(allow_dynamic_lds((const void*)resfuse64_kernel<RF_RES>, 160 * 1024, lds_set));
@@ -2695,6 +2719,9 @@ int launch_ddim_down1(const PackedConv& out_conv, const PackedConv& down1, const
     a.sched_z = const_cast<float*>(z_in); a.sched_z_out = z_out; a.sched_coef = coef;
     a.step_ptr = ctl; a.sched_ticket = ctl + 4;
     a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.cout = 64;
+#ifdef TAPCONV_STAMP
+    a.dbg_rt = dbg_rt_for("chain");
+#endif
     LDM_TRY(prepare_ddim_down1());
     g_last_kernel = "void ldm::resfuse64_kernel<1>(ldm::TapConvArgs)";
     hipLaunchKernelGGL(resfuse64_kernel<RF_DDIM>, dim3((unsigned)(B * (H / RF_R))), dim3(512), rf_lds(RF_DDIM), stream, a);
