@@ -304,13 +304,14 @@ def test_full_size_chain_is_deterministic(A):
     assert torch.equal(eager, ref) and torch.equal(other, ref)
 
 
-@pytest.mark.parametrize("B,S,steps", [(32, 64, 5), (64, 64, 4), (16, 128, 3)])
+@pytest.mark.parametrize("B,S,steps", [(32, 64, 1), (32, 64, 2), (32, 64, 5), (64, 64, 4), (16, 128, 3)])
 def test_chained_ddim_steps_equal_the_single_step_kernels(A, B, S, steps):
     """bf16 DDIM on 64-pixel-wide latents with at least 128 bands of 16 rows: out_conv, the DDIM update and the NEXT
     step's down1 run as one kernel (the bf16 copy of the state stays in LDS, the f32 state alternates between two
     buffers).  A sampler created under LDM_DDIMCHAIN=0 runs the same steps as out_conv + update and down1: the same
-    arithmetic in the same order, so the final latents must be equal bit for bit - with an odd and an even number of
-    steps (the final state ends in either buffer), eagerly and as a graph."""
+    arithmetic in the same order, so the final latents must be equal bit for bit - with one step (no chained launch at
+    all), two (one chained launch, the last step in place on the second buffer), and odd and even larger counts (the final
+    state ends in either buffer), eagerly and as a graph."""
     w = A.make_synthetic_weights(A.LDMConfig(), 0)
     z0 = torch.randn(B, 64, S, 64, generator=torch.Generator().manual_seed(5)).cuda()
     _say(f"chained ddim steps B={B} H={S} steps={steps}")
